@@ -1,0 +1,171 @@
+/*
+ * rt_hip.h -- C ABI of the MI355X (gfx950) path tracer, librt_hip.so.
+ *
+ * This is the seam a C++ adaptor behind the reference's tracer plug-in interface calls:
+ *   ITraceMethod::trace(const Texture2D&, Texture2D&, int)   Renderer/RenderInterfaces.hpp:5-12
+ *   ILoadMethod::load()                                      Renderer/RenderInterfaces.hpp:15-22
+ * The reference has no FFI of its own for this path (its trace methods call Trace::CastRay
+ * directly); each entry point below names the reference code whose job it takes over.
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types.  Every function returns RT_OK (0) or
+ * a negative rt_status and never throws; rt_last_error() gives the text for the calling context.
+ * Host arrays are borrowed for the duration of the call only.  Calls on one context are serialised
+ * by an internal mutex, so trace and upload may come from different threads
+ * (RenderInterfaces.hpp:4-10, 14-20 require that of trace/load).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_NO_DEVICE = -2,
+    RT_ERR_HIP = -3,
+    RT_ERR_NO_SCENE = -4, /* "Scene is not loaded.", Renderer/TraceMethods.cpp:54-56 */
+    RT_ERR_BAD_SCENE = -5,
+    RT_ERR_OUT_OF_MEMORY = -6
+} rt_status;
+
+/* Node kinds carried in rt_node.flags.  0 and 1 are the reference's NODE_INTERNAL / NODE_LEAF
+ * (CPURayTrace/SimplifiedData.hpp:30-36).  RT_NODE_MESH (the reference's unused NODE_MESH value) and
+ * RT_NODE_SPHERE describe the pointer-based scene (CPURayTrace/BVH.hpp:6-12) once flattened. */
+enum {
+    RT_NODE_INTERNAL = 0, /* left/right = child node indices */
+    RT_NODE_LEAF = 1,     /* left = triangle index */
+    RT_NODE_MESH = 2,     /* left = root node of the mesh's inner BVH (CPURayTrace/Mesh.hpp:100) */
+    RT_NODE_SPHERE = 4    /* left = sphere index */
+};
+
+/* Byte-compatible with sd::Node (SimplifiedData.hpp:71-77): 36 bytes, flags in the first byte after
+ * the box; the three padding bytes are ignored. */
+typedef struct rt_node {
+    uint32_t left;
+    uint32_t right;
+    float pmin[3];
+    float pmax[3];
+    uint8_t flags;
+    uint8_t pad_[3];
+} rt_node;
+
+/* Byte-compatible with sd::Triangle (SimplifiedData.hpp:82-88): 100 bytes. */
+typedef struct rt_tri {
+    float pos[3][3];
+    float nrm[3][3];
+    float uv[3][2];
+    uint16_t mat; /* sd path: the Matierals enumerator; old path: index into the material table */
+    uint16_t pad_;
+} rt_tri;
+
+/* Sphere of CPURayTrace/Objects.hpp:26-42. */
+typedef struct rt_sphere {
+    float center[3];
+    float radius;
+    uint32_t mat;     /* index into the material table */
+    uint32_t prim_id; /* value reported in the primary-id image */
+} rt_sphere;
+
+enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_EMIT = 2, RT_MAT_DIELECTRIC = 4 };
+
+/* Materials of CPURayTrace/Materials/{Lambertian,Metal,LightEmit}.hpp plus a dielectric. */
+typedef struct rt_material {
+    uint32_t kind;
+    float albedo[4]; /* albedo, or intensity for RT_MAT_EMIT */
+    float param;     /* Metal: gross; Dielectric: index of refraction */
+} rt_material;
+
+/* Field order of class Camera (Include/Camera.hpp:10-15). */
+typedef struct rt_camera {
+    float focal_length;
+    float position[3];
+    float look_at[3];
+    float width;
+    float height;
+    float aspect_ratio;
+} rt_camera;
+
+enum {
+    RT_EST_SD_LOOP = 0,      /* Trace::CastRay(ray, depth, sd::DataStorage&), CPURayTrace/Trace.cpp:58-96 */
+    RT_EST_OLD_RECURSIVE = 1 /* Trace::CastRay(ray, depth, const Scene&), CPURayTrace/Trace.cpp:31-56 */
+};
+enum {
+    RT_ORDER_RIGHT_FIRST = 0, /* sd::BVH::IntersectLoop pops the right child first, SimplifiedData.cpp:458-459 */
+    RT_ORDER_LEFT_FIRST = 1   /* BVH::intersect / sd::BVH::Intersect recurse left first, BVH.hpp:143-144 */
+};
+
+typedef struct rt_options {
+    int32_t bounce_limit; /* Trace::bounceLimit, CPURayTrace/Trace.hpp:16 */
+    int32_t estimator;    /* RT_EST_* */
+    uint32_t seed;        /* counter RNG seed (replaces Random::generator, Include/Random.hpp:12) */
+    float jitter;         /* perturbStrength, Renderer/TraceMethods.cpp:48 */
+    int32_t tile_rank;    /* this context renders 8x8 tiles k with k % tile_world == tile_rank */
+    int32_t tile_world;   /* 1 = whole image */
+    int32_t collect_stats; /* also count slab / triangle / sphere tests (slower kernel variant) */
+    int32_t reserved_;
+} rt_options;
+
+typedef struct rt_stats {
+    uint64_t rays;      /* closest-hit traversals started, primary + bounces */
+    uint64_t box_tests; /* filled when collect_stats != 0 */
+    uint64_t tri_tests;
+    uint64_t sph_tests;
+    uint64_t tri_hits;  /* traversals that ended on a triangle */
+    float kernel_ms;    /* HIP-event time of the trace kernel on the context's stream */
+    float total_ms;     /* host wall time of the call */
+} rt_stats;
+
+/* Creates a context on HIP device `device`.  Stands in for the constructors of the reference's
+ * trace/load method objects (Renderer/TraceMethods.cpp:44, Renderer/LoadMethods.cpp:54). */
+int rt_create(rt_ctx **out, int device);
+void rt_destroy(rt_ctx *ctx);
+const char *rt_last_error(rt_ctx *ctx);
+
+/* Takes the scene snapshot the reference's load methods take (LoadSdSceneCPU::load,
+ * Renderer/LoadMethods.cpp:55-61; LoadSceneCPU::load, :65-73) and lays it out in HBM.  `nodes`/`tris`
+ * may point straight at sd::NodeStorage::nodes / sd::TriangleStorage::triangles.  `order` says which
+ * child the reference traversal visits first (RT_ORDER_*). */
+int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt_tri *tris,
+                    uint32_t n_tris, const rt_sphere *spheres, uint32_t n_spheres, const rt_material *mats,
+                    uint32_t n_mats, int order);
+
+/* The camera the reference reads live each frame (DIContext.cam, Renderer/TraceMethods.cpp:51-53). */
+int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
+int rt_set_options(rt_ctx *ctx, const rt_options *opt);
+
+/* Zeroes the accumulated image (TracerAsync::resetSamples, Renderer/TracerImpl.cpp:18-22, together
+ * with CPUImageData::resize's zero fill, Renderer/TraceMethods.hpp:31-36). */
+int rt_reset(rt_ctx *ctx);
+
+/* TraceSdSceneCPU::trace / TraceSceneCPU::trace (Renderer/TraceMethods.cpp:45-80, :84-119): renders
+ * samples first_sample .. first_sample+n_samples-1 (first_sample is the reference's 1-based
+ * sampleCount) for every pixel into the context's running-mean image and copies the W*H*4 float mean
+ * to out_rgba_mean (host, row 0 = bottom row, may be NULL).  out_primary_id (host, W*H, may be NULL)
+ * receives the primitive hit by sample first_sample's camera ray, 0xFFFFFFFF for a miss.  The image
+ * is re-zeroed when width/height change. */
+int rt_trace(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *out_rgba_mean,
+             uint32_t *out_primary_id, rt_stats *stats);
+
+/* Same work, asynchronous, into caller-owned DEVICE memory: d_rgba (W*H*4 floats, holds the running
+ * mean before and after; the caller zeroes it for first_sample == 1) and d_primary_id (W*H, may be
+ * NULL).  Enqueued on the context's stream; nothing is copied to the host. */
+int rt_trace_device(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *d_rgba,
+                    uint32_t *d_primary_id);
+/* Replaces the context's stream with a caller-owned hipStream_t (NULL = the default stream). */
+int rt_set_stream(rt_ctx *ctx, void *hip_stream);
+/* Waits for the context's stream and reports the counters and kernel time of the last trace. */
+int rt_sync(rt_ctx *ctx, rt_stats *stats);
+
+/* Library self-description: "rt_hip <version> gfx950". */
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,12 @@
+"""raytracing_amd -- MI355X (gfx950) path tracer behind the plug-in interface of wcg21444/RayTracing.
+
+The compute path is hand-written HIP in csrc/rt_hip.hip behind the C ABI of include/rt_hip.h; the C++
+host side (scene models, BVH builders, plug-in adaptors) is in csrc/host.  This package is the ctypes
+glue harnesses use; importing it requires the built libraries (no CPU fallback exists).
+"""
+from . import _native
+from .scene import (MAT_DIELECTRIC, MAT_EMIT, MAT_LAMBERTIAN, MAT_METAL, OldScene, SdScene)
+from .tracer import (EST_OLD_RECURSIVE, EST_SD_LOOP, MISS, Camera, PluginHarness, Stats, Tracer, TracerError)
+
+__all__ = ["SdScene", "OldScene", "Tracer", "TracerError", "Camera", "Stats", "PluginHarness", "EST_SD_LOOP",
+           "EST_OLD_RECURSIVE", "MISS", "MAT_LAMBERTIAN", "MAT_METAL", "MAT_EMIT", "MAT_DIELECTRIC"]

@@ -1,0 +1,928 @@
+// rt_hip.hip -- MI355X (gfx950) path tracer: device kernels and the C ABI of include/rt_hip.h.
+//
+// What runs on the GPU is the per-pixel loop of the reference's CPU trace methods
+// (Renderer/TraceMethods.cpp:45-119): camera ray generation (Include/Camera.hpp:33-47), closest-hit
+// search over the scene BVH (CPURayTrace/SimplifiedData.cpp:430-462, CPURayTrace/BVH.hpp:124-148),
+// slab / Moller-Trumbore / sphere tests (SimplifiedData.cpp:146-161, :269-307, Objects.hpp:43-72),
+// the two radiance estimators of CPURayTrace/Trace.cpp and the running-mean accumulation.
+//
+// Numerics contract: every value is computed with the same IEEE fp32 operations in the same order as
+// the reference's scalar glm expressions (dot = (x+y)+z, normalize = v*(1/sqrt(dot)), ...), with no
+// fused multiply-add (build with -ffp-contract=off) and correctly rounded divide and sqrt, so hit
+// primitives, hit distances and shaded pixels are reproducible bit for bit on a CPU.
+//
+// Traversal design: the reference visits nodes in one fixed depth-first order that does not depend on
+// the ray (children are never sorted by distance).  The scene is therefore re-laid in HBM in exactly
+// that visiting order as 32-byte records {pMin, pMax, skip, kind}; "descend" is index+1 and "prune"
+// is a jump to the record's skip index, so a lane needs no traversal stack at all and performs
+// exactly the slab and triangle tests the reference performs, in the same order, with the same
+// running closest distance.
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rt_hip.h"
+
+#define RT_HD __host__ __device__ __forceinline__
+#define RT_D __device__ __forceinline__
+
+namespace {
+
+// ------------------------------------------------------------------ fp32 vector helpers (glm order)
+struct f3 {
+    float x, y, z;
+};
+RT_HD f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+RT_HD f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_HD f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_HD f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+RT_HD f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+RT_HD f3 operator*(float s, f3 a) { return f3{s * a.x, s * a.y, s * a.z}; }
+RT_HD f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
+RT_HD float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RT_HD f3 cross3(f3 a, f3 b) { return f3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+RT_HD f3 normalize3(f3 v) { return v * (1.0f / sqrtf(dot3(v, v))); }
+// mat3(c0,c1,c2) * v, row by row
+RT_HD f3 basis_mul(f3 c0, f3 c1, f3 c2, f3 v) {
+    return f3{(c0.x * v.x + c1.x * v.y) + c2.x * v.z, (c0.y * v.x + c1.y * v.y) + c2.y * v.z,
+              (c0.z * v.x + c1.z * v.y) + c2.z * v.z};
+}
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kSphereBit = 0x80000000u;
+constexpr uint32_t KIND_INTERNAL = 0, KIND_TRI = 1, KIND_MESH = 2, KIND_SPHERE = 4;
+
+// ------------------------------------------------------------------ kernel parameters
+struct KParams {
+    const float4 *nodes; // 2 x float4 per node, reference visiting order
+    const float4 *tri_pos; // 3 x float4 per triangle slot: p0, e1, e2, prim id, material
+    const float4 *tri_nrm; // 3 x float4 per triangle slot: n0, n1, n2
+    const float4 *spheres; // 2 x float4 per sphere
+    const float4 *mats;    // 2 x float4 per material
+    float4 *image;
+    uint32_t *primary;
+    unsigned int *queue;
+    unsigned long long *counters; // rays, box, tri, sph, tri_hits
+    uint32_t n_nodes;
+    uint32_t n_my_tiles;
+    int W, H, tiles_x;
+    int tile_rank, tile_world;
+    int first_sample, n_samples;
+    int bounce_limit;
+    uint32_t seed;
+    float jitter;
+    f3 cam_pos, bx, by, bz;
+    float cam_w, cam_h, focal;
+};
+
+// ------------------------------------------------------------------ counter RNG
+RT_D uint32_t pcg(uint32_t v) {
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+RT_D float rng01(uint32_t key, uint32_t dim) {
+    return (float)(pcg(key + dim * 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
+}
+// dimensions: 0..2 camera-ray jitter; bounce b uses 3+4b (roulette), 4+4b, 5+4b (cosine sample), 6+4b (dielectric)
+
+// cos/sin of the cosine-hemisphere sample (Include/Random.hpp:52-53) from fp32 add/mul only:
+// Cody-Waite reduction by pi/2 and the classic minimax polynomials, <= 2 ulp on [0, 2pi].
+RT_D void sincos_poly(float th, float &s, float &c) {
+    int q = (int)(th * 0.636619772f + 0.5f);
+    float qf = (float)q;
+    float r = ((th - qf * 1.5703125f) - qf * 4.837512969970703125e-4f) - qf * 7.54978995489188216e-8f;
+    float z = r * r;
+    float sp = r + (r * z) * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+    float cp = (1.0f - 0.5f * z) + (z * z) * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+    int k = q & 3;
+    s = (k == 0) ? sp : (k == 1) ? cp : (k == 2) ? -sp : -cp;
+    c = (k == 0) ? cp : (k == 1) ? -sp : (k == 2) ? -cp : sp;
+}
+
+// Random::GenerateCosineSemiSphereVector, Include/Random.hpp:41-72
+RT_D f3 cosine_dir(f3 n, float u1, float u2) {
+    float r = sqrtf(u1);
+    float theta = 6.28318530717958647692f * u2;
+    float sn, cs;
+    sincos_poly(theta, sn, cs);
+    float x = r * cs;
+    float y = r * sn;
+    float z = sqrtf(1.0f - u1);
+    f3 T;
+    if (fabsf(n.z) < 0.99f)
+        T = normalize3(cross3(n, mk3(0.0f, 0.0f, 1.0f)));
+    else
+        T = normalize3(cross3(n, mk3(1.0f, 0.0f, 0.0f)));
+    f3 B = cross3(T, n);
+    return basis_mul(T, B, n, mk3(x, y, z));
+}
+
+// Sky gradient, CPURayTrace/Trace.cpp:86-89 == Materials/Sky.hpp:12-14
+RT_D f3 sky_color(f3 dir) {
+    f3 unit = normalize3(dir);
+    float a = 0.5f * (unit.y + 1.0f);
+    return (1.0f - a) * mk3(1.0f, 1.0f, 1.0f) + a * mk3(0.5f, 0.7f, 1.0f);
+}
+
+struct Best {
+    float t, u, v;
+    uint32_t ref; // triangle slot, kSphereBit | sphere index, or kNone
+};
+struct Cnt {
+    unsigned long long rays, box, tri, sph, trih;
+};
+
+// Closest hit in the reference's own visiting order.  One iteration = one node of the reference
+// traversal: slab test against (1e-6, closest.t) (SimplifiedData.cpp:443, BVH.hpp:129), then for a
+// leaf the primitive test and the strict "t < closest.t" update (SimplifiedData.cpp:452, BVH.hpp:137).
+// The per-axis early-outs of the reference slab test only stop early; the accept/reject decision is
+// the final "tMax <= tMin" comparison because tMin never decreases and tMax never increases.
+template <bool OLD, bool STATS>
+RT_D void closest_hit(const KParams &P, const f3 o, const f3 d, const f3 inv, Best &best, Cnt &cnt) {
+    best.t = __builtin_inff();
+    best.u = 0.0f;
+    best.v = 0.0f;
+    best.ref = kNone;
+    Best outer = best;         // OLD: the scene-level closest while inside a mesh's inner BVH
+    uint32_t inner_end = kNone; // OLD: first node index after the current mesh's inner BVH
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const uint32_t n = P.n_nodes;
+    uint32_t idx = 0;
+    while (idx < n) {
+        if (OLD) {
+            if (idx == inner_end) { // Mesh::intersect returned: keep it only if strictly closer (BVH.hpp:137)
+                if (!(best.t < outer.t))
+                    best = outer;
+                inner_end = kNone;
+            }
+        }
+        const float4 a = P.nodes[2 * idx];
+        const float4 b = P.nodes[2 * idx + 1];
+        const uint32_t skip = __float_as_uint(b.z);
+        const uint32_t kind = __float_as_uint(b.w);
+        if (STATS)
+            cnt.box++;
+        float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
+        float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
+        float t0z = (a.z - o.z) * inv.z, t1z = (b.y - o.z) * inv.z;
+        float nearx = nx ? t1x : t0x, farx = nx ? t0x : t1x;
+        float neary = ny ? t1y : t0y, fary = ny ? t0y : t1y;
+        float nearz = nz ? t1z : t0z, farz = nz ? t0z : t1z;
+        // "t0 > tMin ? t0 : tMin" keeps tMin when t0 is NaN, as fmaxf(t0, tMin) does; likewise fminf
+        float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+        float tmax = fminf(farz, fminf(fary, fminf(farx, best.t)));
+        if (tmax <= tmin) {
+            idx = skip;
+            continue;
+        }
+        idx = idx + 1;
+        const uint32_t k = kind & 7u;
+        if (k == KIND_INTERNAL)
+            continue;
+        const uint32_t slot = kind >> 3;
+        if (k == KIND_TRI) {
+            if (STATS)
+                cnt.tri++;
+            const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
+            const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+            const float EPSILON = 1e-7f;
+            f3 h = cross3(d, e2);
+            float det = dot3(e1, h);
+            if (!(det > -EPSILON && det < EPSILON)) {
+                float f = 1.0f / det;
+                f3 s = o - p0;
+                float u = f * dot3(s, h);
+                if (!(u < 0.0f || u > 1.0f)) {
+                    f3 q = cross3(s, e1);
+                    float v = f * dot3(d, q);
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        float t = f * dot3(e2, q);
+                        if (t > EPSILON && t < best.t) {
+                            best.t = t;
+                            best.u = u;
+                            best.v = v;
+                            best.ref = slot;
+                        }
+                    }
+                }
+            }
+        } else if (OLD && k == KIND_SPHERE) { // Sphere::intersect, Objects.hpp:43-72
+            if (STATS)
+                cnt.sph++;
+            const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
+            f3 oc = mk3(s0.x, s0.y, s0.z) - o;
+            float qa = dot3(d, d);
+            float qb = -2.0f * dot3(d, oc);
+            float qc = dot3(oc, oc) - s0.w * s0.w;
+            float disc = qb * qb - 4 * qa * qc;
+            if (!(disc < 0)) {
+                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
+                bool ok = !(t < 0);
+                // a ray that starts inside never hits (Objects.hpp:57-60), except for the dielectric
+                // spheres this build adds, which need the exit point
+                if (!ok && __float_as_uint(s1.z) != 0u) {
+                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
+                    ok = !(t < 0);
+                }
+                if (ok && t < best.t) {
+                    best.t = t;
+                    best.ref = kSphereBit | slot;
+                }
+            }
+        } else if (OLD && k == KIND_MESH) { // Mesh::intersect starts a fresh closest hit (Mesh.hpp:154-160)
+            outer = best;
+            inner_end = skip;
+            best.t = __builtin_inff();
+            best.ref = kNone;
+        }
+    }
+    if (OLD) {
+        if (inner_end != kNone) {
+            if (!(best.t < outer.t))
+                best = outer;
+        }
+    }
+}
+
+struct RayState {
+    f3 o, d, inv;
+};
+RT_D void set_ray(RayState &r, f3 o, f3 d) { // Ray::Ray, CPURayTrace/Ray.hpp:8
+    r.o = o;
+    r.d = d;
+    r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+}
+
+RT_D f3 tri_normal(const KParams &P, uint32_t slot, float u, float v) { // SimplifiedData.cpp:293
+    const float4 m0 = P.tri_nrm[3 * slot], m1 = P.tri_nrm[3 * slot + 1], m2 = P.tri_nrm[3 * slot + 2];
+    const f3 n0 = mk3(m0.x, m0.y, m0.z), n1 = mk3(m0.w, m1.x, m1.y), n2 = mk3(m1.z, m1.w, m2.x);
+    return normalize3((1 - u - v) * n0 + u * n1 + v * n2);
+}
+
+RT_D float reflectance(float cosine, float ri) {
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    float m = 1.0f - cosine;
+    float m2 = m * m;
+    return r0 + (1.0f - r0) * ((m2 * m2) * m);
+}
+
+// One pixel sample with the flat-scene estimator, Trace::CastRay(ray, depth, sd::DataStorage&),
+// CPURayTrace/Trace.cpp:58-96.
+template <bool STATS>
+RT_D float4 sample_sd(const KParams &P, RayState ray, uint32_t key, Cnt &cnt, uint32_t &primary) {
+    float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
+    f3 thr = mk3(1.f, 1.f, 1.f);
+    int depth = 0;
+    while (depth < P.bounce_limit) {
+        const uint32_t dim = 3u + 4u * (uint32_t)depth;
+        depth++;
+        Best hit;
+        cnt.rays++;
+        closest_hit<false, STATS>(P, ray.o, ray.d, ray.inv, hit, cnt);
+        if (hit.ref != kNone) {
+            if (STATS)
+                cnt.trih++;
+            const float4 q2 = P.tri_pos[3 * hit.ref + 2];
+            if (depth == 1)
+                primary = __float_as_uint(q2.y);
+            if (__float_as_uint(q2.z) != 0u)
+                continue; // not LambertianMat: the reference loop re-casts the unchanged ray (Trace.cpp:80-82)
+            f3 N = tri_normal(P, hit.ref, hit.u, hit.v);
+            f3 pos = ray.o + hit.t * ray.d;
+            // Lambertian::Hit, Materials/Lambertian.hpp:35-48
+            f3 bias = N * 1e-5f;
+            float u1 = rng01(key, dim + 1u);
+            float u2 = rng01(key, dim + 2u);
+            f3 nd = cosine_dir(N, u1, u2);
+            set_ray(ray, pos + bias, nd);
+            thr = thr * mk3(0.9f, 0.6f, 0.5f);
+            continue;
+        }
+        if (depth == 1)
+            primary = kNone;
+        f3 add = thr * sky_color(ray.d);
+        color = make_float4(color.x + add.x, color.y + add.y, color.z + add.z, color.w + 1.0f);
+        break;
+    }
+    return color;
+}
+
+// One pixel sample with the old-scene estimator, Trace::CastRay(ray, depth, const Scene&),
+// CPURayTrace/Trace.cpp:31-56, unrolled into a loop: the recursion multiplies albedo and roulette
+// weights on the way back, the loop multiplies them into a running throughput on the way in.
+template <bool STATS>
+RT_D float4 sample_old(const KParams &P, RayState ray, uint32_t key, Cnt &cnt, uint32_t &primary) {
+    float4 thr = make_float4(1.f, 1.f, 1.f, 1.f);
+    for (int depth = 0;; depth++) {
+        const uint32_t dim = 3u + 4u * (uint32_t)depth;
+        float rr = 1.0f; // Trace.cpp:33, Random::RussianRoulette(0.8f), Include/Random.hpp:74-78
+        if (depth > 1)
+            rr = rng01(key, dim) < 0.8f ? 1.0f / 0.8f : 0.0f;
+        if (depth > P.bounce_limit || rr == 0.0f)
+            return make_float4(0.f, 0.f, 0.f, 0.f);
+        Best hit;
+        cnt.rays++;
+        closest_hit<true, STATS>(P, ray.o, ray.d, ray.inv, hit, cnt);
+        if (hit.ref == kNone) {
+            if (depth == 0)
+                primary = kNone;
+            f3 s = sky_color(ray.d);
+            return make_float4((thr.x * s.x) * rr, (thr.y * s.y) * rr, (thr.z * s.z) * rr, (thr.w * 1.0f) * rr);
+        }
+        f3 pos = ray.o + hit.t * ray.d;
+        f3 N;
+        uint32_t mat, prim;
+        if (hit.ref & kSphereBit) {
+            const uint32_t si = hit.ref & ~kSphereBit;
+            const float4 s0 = P.spheres[2 * si], s1 = P.spheres[2 * si + 1];
+            N = normalize3(pos - mk3(s0.x, s0.y, s0.z));
+            mat = __float_as_uint(s1.x);
+            prim = __float_as_uint(s1.y);
+        } else {
+            if (STATS)
+                cnt.trih++;
+            const float4 q2 = P.tri_pos[3 * hit.ref + 2];
+            N = tri_normal(P, hit.ref, hit.u, hit.v);
+            prim = __float_as_uint(q2.y);
+            mat = __float_as_uint(q2.z);
+        }
+        if (depth == 0)
+            primary = prim;
+        const float4 m0 = P.mats[2 * mat], m1 = P.mats[2 * mat + 1];
+        const uint32_t kind = __float_as_uint(m1.x);
+        const float param = m1.y;
+        thr = make_float4((thr.x * m0.x) * rr, (thr.y * m0.y) * rr, (thr.z * m0.z) * rr, (thr.w * m0.w) * rr);
+        if (kind == RT_MAT_EMIT) // LightEmit::getIrradiance, Materials/LightEmit.hpp:11-14
+            return thr;
+        if (kind == RT_MAT_DIELECTRIC) { // no reference counterpart: Snell + Schlick
+            f3 unit = normalize3(ray.d);
+            bool front = dot3(unit, N) < 0.0f;
+            f3 n = front ? N : -N;
+            float ri = front ? (1.0f / param) : param;
+            float dn = dot3(-unit, n);
+            float cosT = (1.0f < dn) ? 1.0f : dn;
+            float sinT = sqrtf(1.0f - cosT * cosT);
+            bool cannot = ri * sinT > 1.0f;
+            float pick = rng01(key, dim + 3u);
+            f3 bias = n * 1e-4f;
+            if (cannot || reflectance(cosT, ri) > pick) {
+                f3 refl = unit - n * dot3(unit, n) * 2.f;
+                set_ray(ray, pos + bias, refl);
+            } else {
+                f3 perp = ri * (unit + cosT * n);
+                f3 par = n * -sqrtf(fabsf(1.0f - dot3(perp, perp)));
+                set_ray(ray, pos - bias, perp + par);
+            }
+            continue;
+        }
+        // Lambertian::getIrradiance (Materials/Lambertian.hpp:16-29) / Metal::getIrradiance (Metal.hpp:15-31)
+        f3 bias = N * 1e-4f;
+        float u1 = rng01(key, dim + 1u);
+        float u2 = rng01(key, dim + 2u);
+        f3 rnd = cosine_dir(N, u1, u2);
+        if (kind == RT_MAT_METAL) {
+            f3 refl = ray.d - N * dot3(ray.d, N) * 2.f;
+            f3 nd = normalize3(rnd * param + refl * (1 - param));
+            set_ray(ray, pos + bias, nd);
+        } else {
+            set_ray(ray, pos + bias, rnd);
+        }
+    }
+}
+
+RT_D unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Persistent wave64 kernel.  Each wave draws 8x8-pixel tiles from one atomic counter; a lane owns one
+// pixel of the tile and runs that pixel's samples in order, which keeps the reference's running mean
+// "pixel = (pixel*(n-1) + new)/n" (Renderer/TraceMethods.cpp:59) in registers.  Finished lanes drop
+// out of the wave's exec mask; the wave leaves a loop when the mask is empty.
+template <bool OLD, bool STATS>
+__global__ void __launch_bounds__(256) k_trace(const KParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull};
+    for (;;) {
+        unsigned int j = 0;
+        if (lane == 0)
+            j = atomicAdd(P.queue, 1u);
+        j = __builtin_amdgcn_readfirstlane(j);
+        if (j >= P.n_my_tiles)
+            break;
+        const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
+        const int x = (int)(tile % (uint32_t)P.tiles_x) * 8 + (int)(lane & 7u);
+        const int y = (int)(tile / (uint32_t)P.tiles_x) * 8 + (int)(lane >> 3);
+        if (x < P.W && y < P.H) {
+            const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+            float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (P.first_sample > 1)
+                px = P.image[pixel];
+            // CPUImageData::uvAt, Renderer/TraceMethods.hpp:30; Camera::getRayDirction, Camera.hpp:33-47
+            const float u = (float)x / (float)P.W, v = (float)y / (float)P.H;
+            f3 view = normalize3(mk3(u * P.cam_w - P.cam_w / 2, v * P.cam_h - P.cam_h / 2, P.focal));
+            view.x = -view.x;
+            const f3 dir0 = basis_mul(P.bx, P.by, P.bz, view);
+            const uint32_t pkey = pcg(pcg(P.seed) + pixel);
+            for (int n = P.first_sample; n < P.first_sample + P.n_samples; n++) {
+                const uint32_t key = pcg(pkey + (uint32_t)n);
+                // glm::linearRand(vec3(-s), vec3(s)), Include/Random.hpp:13-16
+                const float s = P.jitter;
+                f3 jit = mk3(rng01(key, 0u) * (s - (-s)) + (-s), rng01(key, 1u) * (s - (-s)) + (-s),
+                             rng01(key, 2u) * (s - (-s)) + (-s));
+                RayState ray;
+                set_ray(ray, P.cam_pos, dir0 + jit);
+                uint32_t prim = kNone;
+                float4 c = OLD ? sample_old<STATS>(P, ray, key, cnt, prim) : sample_sd<STATS>(P, ray, key, cnt, prim);
+                if (P.primary != nullptr && n == P.first_sample)
+                    P.primary[pixel] = prim;
+                const float nm1 = static_cast<float>((float)n - 1.f), nf = static_cast<float>(n);
+                px = make_float4((px.x * nm1 + c.x) / nf, (px.y * nm1 + c.y) / nf, (px.z * nm1 + c.z) / nf,
+                                 (px.w * nm1 + c.w) / nf);
+            }
+            P.image[pixel] = px;
+        }
+    }
+    unsigned long long r = wave_sum(cnt.rays);
+    if (lane == 0)
+        atomicAdd(&P.counters[0], r);
+    if (STATS) {
+        unsigned long long b = wave_sum(cnt.box), t = wave_sum(cnt.tri), s = wave_sum(cnt.sph), h = wave_sum(cnt.trih);
+        if (lane == 0) {
+            atomicAdd(&P.counters[1], b);
+            atomicAdd(&P.counters[2], t);
+            atomicAdd(&P.counters[3], s);
+            atomicAdd(&P.counters[4], h);
+        }
+    }
+}
+
+} // namespace
+
+// ===================================================================== host side of the C ABI
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::mutex mu;
+    std::string err;
+    // scene in HBM
+    float4 *d_nodes = nullptr, *d_tri_pos = nullptr, *d_tri_nrm = nullptr, *d_spheres = nullptr, *d_mats = nullptr;
+    uint32_t n_nodes = 0;
+    bool has_scene = false;
+    rt_camera cam;
+    bool has_camera = false;
+    rt_options opt;
+    // running-mean image owned by the context (rt_trace)
+    float4 *d_image = nullptr;
+    uint32_t *d_primary = nullptr;
+    int img_w = 0, img_h = 0;
+    // work queue head and counters
+    unsigned int *d_queue = nullptr;
+    unsigned long long *d_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int num_cus = 0;
+    int blocks_per_cu[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(rt_ctx *ctx, int code, const std::string &msg) {
+    if (ctx)
+        ctx->err = msg;
+    return code;
+}
+#define RT_HIP_CHECK(ctx, expr)                                                                               \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,                   \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                   \
+    } while (0)
+
+void free_scene(rt_ctx *c) {
+    if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_tri_pos) (void)hipFree(c->d_tri_pos);
+    if (c->d_tri_nrm) (void)hipFree(c->d_tri_nrm);
+    if (c->d_spheres) (void)hipFree(c->d_spheres);
+    if (c->d_mats) (void)hipFree(c->d_mats);
+    c->d_nodes = c->d_tri_pos = c->d_tri_nrm = c->d_spheres = c->d_mats = nullptr;
+    c->n_nodes = 0;
+    c->has_scene = false;
+}
+
+inline float u2f(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+template <class T> int upload(rt_ctx *ctx, float4 **dst, const std::vector<T> &src) {
+    size_t bytes = src.size() * sizeof(T);
+    if (bytes == 0)
+        bytes = 16;
+    RT_HIP_CHECK(ctx, hipMalloc((void **)dst, bytes));
+    if (!src.empty())
+        RT_HIP_CHECK(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+template <bool OLD, bool STATS> int occupancy(int *out) {
+    int n = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<OLD, STATS>, 256, 0);
+    if (e != hipSuccess || n < 1)
+        n = 1;
+    if (n > 8)
+        n = 8;
+    *out = n;
+    return 0;
+}
+
+int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim) {
+    if (!ctx->has_scene)
+        return fail(ctx, RT_ERR_NO_SCENE, "Scene is not loaded.");
+    if (!ctx->has_camera)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "camera not set");
+    if (W <= 0 || H <= 0 || first < 1 || count < 0 || (long long)W * H > 0x7FFFFFFFll)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad width/height/sample range");
+    if (d_img == nullptr)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null image");
+    const rt_options &o = ctx->opt;
+    KParams P;
+    P.nodes = ctx->d_nodes;
+    P.tri_pos = ctx->d_tri_pos;
+    P.tri_nrm = ctx->d_tri_nrm;
+    P.spheres = ctx->d_spheres;
+    P.mats = ctx->d_mats;
+    P.image = d_img;
+    P.primary = d_prim;
+    P.queue = ctx->d_queue;
+    P.counters = ctx->d_counters;
+    P.n_nodes = ctx->n_nodes;
+    P.W = W;
+    P.H = H;
+    P.tiles_x = (W + 7) / 8;
+    const uint32_t tiles = (uint32_t)P.tiles_x * (uint32_t)((H + 7) / 8);
+    P.tile_rank = o.tile_rank;
+    P.tile_world = o.tile_world;
+    P.n_my_tiles = tiles > (uint32_t)o.tile_rank ? (tiles - (uint32_t)o.tile_rank + (uint32_t)o.tile_world - 1) / (uint32_t)o.tile_world : 0u;
+    P.first_sample = first;
+    P.n_samples = count;
+    P.bounce_limit = o.bounce_limit;
+    P.seed = o.seed;
+    P.jitter = o.jitter;
+    // camera basis of Camera::getRayDirction (Include/Camera.hpp:40-44); it is the same for every pixel
+    const rt_camera &c = ctx->cam;
+    f3 pos = mk3(c.position[0], c.position[1], c.position[2]);
+    f3 look = mk3(c.look_at[0], c.look_at[1], c.look_at[2]);
+    f3 z = normalize3(look - pos);
+    f3 x = normalize3(cross3(mk3(0.f, 1.f, 0.f), z));
+    f3 y = cross3(z, x);
+    P.cam_pos = pos;
+    P.bx = x;
+    P.by = y;
+    P.bz = z;
+    P.cam_w = c.width;
+    P.cam_h = c.height;
+    P.focal = c.focal_length;
+
+    RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, 64, ctx->stream));
+    RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 64, ctx->stream));
+    const bool old = o.estimator == RT_EST_OLD_RECURSIVE;
+    const bool st = o.collect_stats != 0;
+    const int variant = (old ? 2 : 0) + (st ? 1 : 0);
+    uint32_t waves_needed = P.n_my_tiles;
+    uint32_t blocks = (uint32_t)ctx->num_cus * (uint32_t)ctx->blocks_per_cu[variant];
+    if (blocks > (waves_needed + 3) / 4)
+        blocks = (waves_needed + 3) / 4;
+    if (blocks < 1)
+        blocks = 1;
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    dim3 grid(blocks), block(256);
+    switch (variant) {
+    case 0: hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, ctx->stream, P); break;
+    case 1: hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, ctx->stream, P); break;
+    case 2: hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, ctx->stream, P); break;
+    default: hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, ctx->stream, P); break;
+    }
+    RT_HIP_CHECK(ctx, hipGetLastError());
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    return RT_OK;
+}
+
+int sync_and_stats(rt_ctx *ctx, rt_stats *stats) {
+    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        if (ctx->timed) {
+            unsigned long long h[5];
+            RT_HIP_CHECK(ctx, hipMemcpy(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+            stats->rays = h[0];
+            stats->box_tests = h[1];
+            stats->tri_tests = h[2];
+            stats->sph_tests = h[3];
+            stats->tri_hits = h[4];
+            float ms = 0.f;
+            RT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            stats->kernel_ms = ms;
+        }
+    }
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_version(void) { return "rt_hip 0.1 gfx950"; }
+
+int rt_create(rt_ctx **out, int device) {
+    if (!out)
+        return RT_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+        return RT_ERR_NO_DEVICE;
+    rt_ctx *ctx = new rt_ctx();
+    ctx->device = device;
+    std::memset(&ctx->cam, 0, sizeof(ctx->cam));
+    ctx->opt = rt_options{4, RT_EST_SD_LOOP, 1u, 0.001f, 0, 1, 0, 0};
+    auto bail = [&](const char *what) {
+        std::fprintf(stderr, "rt_create: %s failed\n", what);
+        delete ctx;
+        return RT_ERR_HIP;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
+    ctx->own_stream = true;
+    if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void **)&ctx->d_counters, 64) != hipSuccess) return bail("hipMalloc");
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) return bail("hipEventCreate");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail("hipGetDeviceProperties");
+    ctx->num_cus = prop.multiProcessorCount;
+    occupancy<false, false>(&ctx->blocks_per_cu[0]);
+    occupancy<false, true>(&ctx->blocks_per_cu[1]);
+    occupancy<true, false>(&ctx->blocks_per_cu[2]);
+    occupancy<true, true>(&ctx->blocks_per_cu[3]);
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx *ctx) {
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    if (ctx->d_image) (void)hipFree(ctx->d_image);
+    if (ctx->d_primary) (void)hipFree(ctx->d_primary);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *rt_last_error(rt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt_tri *tris,
+                    uint32_t n_tris, const rt_sphere *spheres, uint32_t n_spheres, const rt_material *mats,
+                    uint32_t n_mats, int order) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!nodes || n_nodes == 0 || root >= n_nodes)
+        return fail(ctx, RT_ERR_BAD_SCENE, "Build Failed. end - start <= 0 (empty node array or bad root)");
+    if ((n_tris && !tris) || (n_spheres && !spheres) || (n_mats && !mats))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null primitive array");
+    if (order != RT_ORDER_RIGHT_FIRST && order != RT_ORDER_LEFT_FIRST)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad traversal order");
+    if (n_tris >= (1u << 29) || n_spheres >= (1u << 29))
+        return fail(ctx, RT_ERR_BAD_SCENE, "too many primitives");
+
+    // 1. Walk the tree once in the reference's visiting order and record that order.
+    std::vector<uint32_t> order_of; // emission position -> node index
+    std::vector<uint32_t> pos_of(n_nodes, kNone);
+    order_of.reserve(n_nodes);
+    std::vector<uint32_t> stack;
+    stack.push_back(root);
+    while (!stack.empty()) {
+        uint32_t ni = stack.back();
+        stack.pop_back();
+        if (ni >= n_nodes)
+            return fail(ctx, RT_ERR_BAD_SCENE, "node index out of range");
+        if (pos_of[ni] != kNone)
+            return fail(ctx, RT_ERR_BAD_SCENE, "node referenced twice (not a tree)");
+        pos_of[ni] = (uint32_t)order_of.size();
+        order_of.push_back(ni);
+        const rt_node &nd = nodes[ni];
+        switch (nd.flags) {
+        case RT_NODE_INTERNAL:
+            if (order == RT_ORDER_RIGHT_FIRST) {
+                stack.push_back(nd.left);
+                stack.push_back(nd.right);
+            } else {
+                stack.push_back(nd.right);
+                stack.push_back(nd.left);
+            }
+            break;
+        case RT_NODE_LEAF:
+            if (nd.left >= n_tris)
+                return fail(ctx, RT_ERR_BAD_SCENE, "triangle index out of range");
+            break;
+        case RT_NODE_SPHERE:
+            if (nd.left >= n_spheres)
+                return fail(ctx, RT_ERR_BAD_SCENE, "sphere index out of range");
+            break;
+        case RT_NODE_MESH:
+            stack.push_back(nd.left);
+            break;
+        default:
+            return fail(ctx, RT_ERR_BAD_SCENE, "unknown node kind");
+        }
+    }
+    const uint32_t m = (uint32_t)order_of.size();
+    // 2. Subtree sizes, children before parents (children are emitted after their parent).
+    std::vector<uint32_t> size(m, 1);
+    for (uint32_t p = m; p-- > 0;) {
+        const rt_node &nd = nodes[order_of[p]];
+        if (nd.flags == RT_NODE_INTERNAL)
+            size[p] = 1 + size[pos_of[nd.left]] + size[pos_of[nd.right]];
+        else if (nd.flags == RT_NODE_MESH)
+            size[p] = 1 + size[pos_of[nd.left]];
+    }
+    // 3. Emit node records and the triangle arrays in leaf-visit order.
+    std::vector<float4> dn(2 * (size_t)m);
+    std::vector<float4> tp, tn, sp(2 * (size_t)n_spheres), mt(2 * (size_t)n_mats);
+    tp.reserve(3 * (size_t)n_tris);
+    tn.reserve(3 * (size_t)n_tris);
+    uint32_t slot = 0;
+    for (uint32_t p = 0; p < m; p++) {
+        const uint32_t ni = order_of[p];
+        const rt_node &nd = nodes[ni];
+        uint32_t kind = nd.flags, ref = 0;
+        if (nd.flags == RT_NODE_LEAF) {
+            const rt_tri &t = tris[nd.left];
+            if (n_mats && t.mat >= n_mats)
+                return fail(ctx, RT_ERR_BAD_SCENE, "triangle material out of range");
+            ref = slot++;
+            // edges are the same fp32 subtractions the triangle test starts with (SimplifiedData.cpp:272-273)
+            const float e1x = t.pos[1][0] - t.pos[0][0], e1y = t.pos[1][1] - t.pos[0][1], e1z = t.pos[1][2] - t.pos[0][2];
+            const float e2x = t.pos[2][0] - t.pos[0][0], e2y = t.pos[2][1] - t.pos[0][1], e2z = t.pos[2][2] - t.pos[0][2];
+            tp.push_back(make_float4(t.pos[0][0], t.pos[0][1], t.pos[0][2], e1x));
+            tp.push_back(make_float4(e1y, e1z, e2x, e2y));
+            tp.push_back(make_float4(e2z, u2f(nd.left), u2f((uint32_t)t.mat), 0.f));
+            tn.push_back(make_float4(t.nrm[0][0], t.nrm[0][1], t.nrm[0][2], t.nrm[1][0]));
+            tn.push_back(make_float4(t.nrm[1][1], t.nrm[1][2], t.nrm[2][0], t.nrm[2][1]));
+            tn.push_back(make_float4(t.nrm[2][2], 0.f, 0.f, 0.f));
+        } else if (nd.flags == RT_NODE_SPHERE) {
+            ref = nd.left;
+        }
+        dn[2 * (size_t)p] = make_float4(nd.pmin[0], nd.pmin[1], nd.pmin[2], nd.pmax[0]);
+        dn[2 * (size_t)p + 1] = make_float4(nd.pmax[1], nd.pmax[2], u2f(p + size[p]), u2f((ref << 3) | kind));
+    }
+    for (uint32_t i = 0; i < n_mats; i++) {
+        mt[2 * (size_t)i] = make_float4(mats[i].albedo[0], mats[i].albedo[1], mats[i].albedo[2], mats[i].albedo[3]);
+        mt[2 * (size_t)i + 1] = make_float4(u2f(mats[i].kind), mats[i].param, 0.f, 0.f);
+    }
+    for (uint32_t i = 0; i < n_spheres; i++) {
+        if (spheres[i].mat >= n_mats)
+            return fail(ctx, RT_ERR_BAD_SCENE, "sphere material out of range");
+        const uint32_t dielectric = mats[spheres[i].mat].kind == RT_MAT_DIELECTRIC ? 1u : 0u;
+        sp[2 * (size_t)i] = make_float4(spheres[i].center[0], spheres[i].center[1], spheres[i].center[2], spheres[i].radius);
+        sp[2 * (size_t)i + 1] = make_float4(u2f(spheres[i].mat), u2f(spheres[i].prim_id), u2f(dielectric), 0.f);
+    }
+
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+    int rc;
+    if ((rc = upload(ctx, &ctx->d_nodes, dn)) != RT_OK || (rc = upload(ctx, &ctx->d_tri_pos, tp)) != RT_OK ||
+        (rc = upload(ctx, &ctx->d_tri_nrm, tn)) != RT_OK || (rc = upload(ctx, &ctx->d_spheres, sp)) != RT_OK ||
+        (rc = upload(ctx, &ctx->d_mats, mt)) != RT_OK) {
+        free_scene(ctx);
+        return rc;
+    }
+    ctx->n_nodes = m;
+    ctx->has_scene = true;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_ctx *ctx, const rt_camera *cam) {
+    if (!ctx || !cam)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->cam = *cam;
+    ctx->has_camera = true;
+    return RT_OK;
+}
+
+int rt_set_options(rt_ctx *ctx, const rt_options *opt) {
+    if (!ctx || !opt)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (opt->bounce_limit < 0 || opt->tile_world < 1 || opt->tile_rank < 0 || opt->tile_rank >= opt->tile_world ||
+        (opt->estimator != RT_EST_SD_LOOP && opt->estimator != RT_EST_OLD_RECURSIVE))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad options");
+    ctx->opt = *opt;
+    return RT_OK;
+}
+
+int rt_reset(rt_ctx *ctx) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (ctx->d_image)
+        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_image, 0, (size_t)ctx->img_w * ctx->img_h * sizeof(float4), ctx->stream));
+    return RT_OK;
+}
+
+int rt_trace(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *out_rgba_mean,
+             uint32_t *out_primary_id, rt_stats *stats) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    auto t0 = std::chrono::steady_clock::now();
+    if (width <= 0 || height <= 0 || (long long)width * height > 0x7FFFFFFFll)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad width/height");
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)width * (size_t)height;
+    if (width != ctx->img_w || height != ctx->img_h || !ctx->d_image) {
+        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_image) (void)hipFree(ctx->d_image);
+        if (ctx->d_primary) (void)hipFree(ctx->d_primary);
+        ctx->d_image = nullptr;
+        ctx->d_primary = nullptr;
+        ctx->img_w = ctx->img_h = 0;
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_image, px * sizeof(float4)));
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_primary, px * sizeof(uint32_t)));
+        ctx->img_w = width;
+        ctx->img_h = height;
+        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_image, 0, px * sizeof(float4), ctx->stream));
+    }
+    if (first_sample == 1)
+        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_image, 0, px * sizeof(float4), ctx->stream));
+    if (out_primary_id)
+        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_primary, 0xFF, px * sizeof(uint32_t), ctx->stream));
+    int rc = launch_trace(ctx, width, height, first_sample, n_samples, ctx->d_image, out_primary_id ? ctx->d_primary : nullptr);
+    if (rc != RT_OK)
+        return rc;
+    if (out_rgba_mean)
+        RT_HIP_CHECK(ctx, hipMemcpyAsync(out_rgba_mean, ctx->d_image, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_primary_id)
+        RT_HIP_CHECK(ctx, hipMemcpyAsync(out_primary_id, ctx->d_primary, px * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    rc = sync_and_stats(ctx, stats);
+    if (rc != RT_OK)
+        return rc;
+    if (stats)
+        stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int rt_trace_device(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *d_rgba,
+                    uint32_t *d_primary_id) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return launch_trace(ctx, width, height, first_sample, n_samples, (float4 *)d_rgba, d_primary_id);
+}
+
+int rt_set_stream(rt_ctx *ctx, void *hip_stream) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx *ctx, rt_stats *stats) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return sync_and_stats(ctx, stats);
+}
+
+} // extern "C"

@@ -1,0 +1,167 @@
+"""Host-side scenes (built by the C++ code in csrc/host) as Python objects."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+NODE_DTYPE = np.dtype([("left", "<u4"), ("right", "<u4"), ("pmin", "<f4", 3), ("pmax", "<f4", 3), ("flags", "u1"),
+                       ("pad_", "u1", 3)])
+TRI_DTYPE = np.dtype([("pos", "<f4", (3, 3)), ("nrm", "<f4", (3, 3)), ("uv", "<f4", (3, 2)), ("mat", "<u2"),
+                      ("pad_", "<u2")])
+SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("mat", "<u4"), ("prim_id", "<u4")])
+MATERIAL_DTYPE = np.dtype([("kind", "<u4"), ("albedo", "<f4", 4), ("param", "<f4")])
+assert NODE_DTYPE.itemsize == 36 and TRI_DTYPE.itemsize == 100
+
+MAT_LAMBERTIAN, MAT_METAL, MAT_EMIT, MAT_DIELECTRIC = 0, 1, 2, 4
+ORDER_RIGHT_FIRST, ORDER_LEFT_FIRST = 0, 1
+
+
+def _err():
+    return N.host().rth_last_error().decode()
+
+
+def _view(ptr, count, dtype):
+    if count == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_uint8 * (count * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class SdScene:
+    """The reference's flat-array scene (sd::Scene): triangle meshes under a median-split BVH."""
+
+    order = ORDER_RIGHT_FIRST  # sd::BVH::IntersectLoop pops the right child first
+
+    def __init__(self):
+        self._h = N.host().rth_sd_create()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.host().rth_sd_destroy(self._h)
+            self._h = None
+
+    def load_obj(self, path):
+        if N.host().rth_sd_load_obj(self._h, str(path).encode()) != 0:
+            raise RuntimeError(_err())
+        return self
+
+    def add_model(self, tris24, mesh_sizes=None):
+        t = np.ascontiguousarray(tris24, dtype=np.float32).reshape(-1, 24)
+        ms = np.ascontiguousarray(mesh_sizes if mesh_sizes is not None else [len(t)], dtype=np.uint32)
+        assert int(ms.sum()) == len(t)
+        if N.host().rth_sd_add_model(self._h, _fp(t), ms.ctypes.data_as(C.POINTER(C.c_uint32)), len(ms)) != 0:
+            raise RuntimeError(_err())
+        return self
+
+    def finalize(self):
+        if N.host().rth_sd_finalize(self._h) != 0:
+            raise RuntimeError(_err())
+        return self
+
+    def counts(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        N.host().rth_sd_counts(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    @property
+    def root(self):
+        return self.counts()[2]
+
+    def nodes(self):
+        return _view(N.host().rth_sd_nodes(self._h), self.counts()[0], NODE_DTYPE)
+
+    def tris(self):
+        return _view(N.host().rth_sd_tris(self._h), self.counts()[1], TRI_DTYPE)
+
+    def spheres(self):
+        return np.zeros(0, dtype=SPHERE_DTYPE)
+
+    def materials(self):
+        return np.zeros(0, dtype=MATERIAL_DTYPE)
+
+    def flat(self):
+        n, t, _ = self.counts()
+        a = np.zeros((n, 9), dtype=np.float32)
+        b = np.zeros((t, 25), dtype=np.float32)
+        N.host().rth_sd_flat(self._h, _fp(a), _fp(b))
+        return a, b
+
+    def publish(self):
+        """Install as the process-global Storage::SdScene the plug-in load method reads."""
+        if N.host().rth_sd_publish(self._h) != 0:
+            raise RuntimeError(_err())
+
+
+class OldScene:
+    """The reference's pointer-based scene: spheres and meshes with per-object materials."""
+
+    order = ORDER_LEFT_FIRST  # BVH::intersect recurses into the left child first
+
+    def __init__(self):
+        self._h = N.host().rth_old_create()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.host().rth_old_destroy(self._h)
+            self._h = None
+
+    def add_sphere(self, center, radius, kind, albedo=(1, 1, 1, 1), param=0.0):
+        c = np.ascontiguousarray(center, dtype=np.float32)
+        a = np.ascontiguousarray(albedo, dtype=np.float32)
+        if N.host().rth_old_add_sphere(self._h, _fp(c), radius, kind, _fp(a), param) != 0:
+            raise RuntimeError(_err())
+        return self
+
+    def add_mesh(self, tris24, kind, albedo=(1, 1, 1, 1), param=0.0):
+        t = np.ascontiguousarray(tris24, dtype=np.float32).reshape(-1, 24)
+        a = np.ascontiguousarray(albedo, dtype=np.float32)
+        if N.host().rth_old_add_mesh(self._h, _fp(t), len(t), kind, _fp(a), param) != 0:
+            raise RuntimeError(_err())
+        return self
+
+    def add_obj(self, path, kind, albedo=(1, 1, 1, 1), param=0.0):
+        a = np.ascontiguousarray(albedo, dtype=np.float32)
+        if N.host().rth_old_add_obj(self._h, str(path).encode(), kind, _fp(a), param) != 0:
+            raise RuntimeError(_err())
+        return self
+
+    def build(self):
+        if N.host().rth_old_build(self._h) != 0:
+            raise RuntimeError(_err())
+        return self
+
+    finalize = build
+
+    def counts5(self):
+        v = [C.c_uint32() for _ in range(5)]
+        N.host().rth_old_counts(self._h, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
+
+    def counts(self):
+        n, t, s, m, r = self.counts5()
+        return n, t, r
+
+    @property
+    def root(self):
+        return self.counts5()[4]
+
+    def nodes(self):
+        return _view(N.host().rth_old_nodes(self._h), self.counts5()[0], NODE_DTYPE)
+
+    def tris(self):
+        return _view(N.host().rth_old_tris(self._h), self.counts5()[1], TRI_DTYPE)
+
+    def spheres(self):
+        return _view(N.host().rth_old_spheres(self._h), self.counts5()[2], SPHERE_DTYPE)
+
+    def materials(self):
+        return _view(N.host().rth_old_materials(self._h), self.counts5()[3], MATERIAL_DTYPE)
+
+    def publish(self):
+        if N.host().rth_old_publish(self._h) != 0:
+            raise RuntimeError(_err())

@@ -1,0 +1,65 @@
+"""Shared helpers for the tests: build the same scene for the product and for the oracle."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import raytracing_amd as R  # noqa: E402
+from oracle import objparse, oracle as O  # noqa: E402
+from raytracing_amd import workloads as WL  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def oracle_camera(cam):
+    return O.make_camera(cam.focal_length, cam.position, cam.look_at, cam.width, cam.aspect_ratio)
+
+
+def oracle_sd_scene(obj_paths):
+    s = O.SdScene()
+    for p in obj_paths:
+        tris, sizes = objparse.load_obj(p)
+        s.add_model(tris, sizes)
+    s.finalize()
+    return s
+
+
+def product_sd_scene(obj_paths):
+    s = R.SdScene()
+    for p in obj_paths:
+        s.load_obj(p)
+    return s.finalize()
+
+
+def oracle_old_scene(spheres, meshes=()):
+    s = O.OldScene()
+    for c, rad, kind, alb, param in spheres:
+        s.add_sphere(c, rad, kind, alb, param)
+    for tris, kind, alb, param in meshes:
+        s.add_mesh(tris, kind, alb, param)
+    s.build()
+    return s
+
+
+def product_old_scene(spheres, meshes=()):
+    s = R.OldScene()
+    for c, rad, kind, alb, param in spheres:
+        s.add_sphere(c, rad, kind, alb, param)
+    for tris, kind, alb, param in meshes:
+        s.add_mesh(tris, kind, alb, param)
+    return s.build()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def psnr(a, b):
+    a = np.clip(a[..., :3], 0, 1).astype(np.float64)
+    b = np.clip(b[..., :3], 0, 1).astype(np.float64)
+    mse = np.mean((a - b) ** 2)
+    return 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)

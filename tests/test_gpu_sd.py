@@ -1,0 +1,132 @@
+"""GPU parity tests for the flat-array ("sd") path, through the C ABI (rt_trace).
+
+Bar: bit-exact.  Primary-hit primitive ids, slab/triangle test counts and every float of the shaded
+running-mean image must equal the oracle's (oracle trig = the polynomial cos/sin the kernel uses);
+against the oracle's libm cos/sin the stated tolerance is |gpu-cpu| <= 1e-4 + 1e-3*|cpu| on >= 99.9 %
+of the pixels.
+"""
+import numpy as np
+import pytest
+
+from helpers import O, R, WL, bits, oracle_camera, oracle_sd_scene, product_sd_scene, psnr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tracer():
+    t = R.Tracer(0)
+    yield t
+    t.close()
+
+
+@pytest.fixture(scope="module")
+def dragon2426(tracer):
+    return product_sd_scene([WL.DRAGON_2426]), oracle_sd_scene([WL.DRAGON_2426])
+
+
+def test_primary_ids_dragon2426_400x225(tracer, dragon2426):
+    ps, os_ = dragon2426
+    tracer.upload(ps)
+    tracer.set_camera(WL.DRAGON_2426_CAMERA)
+    tracer.set_options(bounce_limit=8, jitter=0.0, collect_stats=True)
+    img, prim, st = tracer.trace(400, 225, 1, 1, want_primary=True)
+    opt = O.make_options(bounce_limit=8, jitter=0.0, trig=O.TRIG_POLY)
+    oimg, oprim, ost = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, 400, 225, 1, 1, want_primary=True)
+    assert (prim != R.MISS).sum() > 1000
+    assert np.count_nonzero(prim != oprim) == 0
+    assert (st.rays, st.box_tests, st.tri_tests, st.tri_hits) == (ost.rays, ost.box_tests, ost.tri_tests, ost.tri_hits)
+    assert np.array_equal(bits(img), bits(oimg))
+
+
+def test_primary_ids_dragon2426_1080p(tracer, dragon2426):
+    ps, os_ = dragon2426
+    tracer.upload(ps)
+    for cam in (WL.DRAGON_2426_CAMERA, WL.DEFAULT_CAMERA):
+        tracer.set_camera(cam)
+        tracer.set_options(bounce_limit=1, jitter=0.0)
+        _, prim, st = tracer.trace(1920, 1080, 1, 1, want_image=False, want_primary=True)
+        opt = O.make_options(bounce_limit=1, jitter=0.0)
+        _, oprim, ost = os_.render(oracle_camera(cam), opt, 1920, 1080, 1, 1, want_primary=True)
+        assert st.rays == ost.rays == 1920 * 1080
+        assert np.count_nonzero(prim != oprim) == 0
+
+
+def test_shaded_image_bit_exact(tracer, dragon2426):
+    ps, os_ = dragon2426
+    tracer.upload(ps)
+    tracer.set_camera(WL.DRAGON_2426_CAMERA)
+    tracer.set_options(bounce_limit=8, seed=7, jitter=0.001, collect_stats=True)
+    img, _, st = tracer.trace(320, 180, 1, 8)
+    opt = O.make_options(bounce_limit=8, seed=7, jitter=0.001, trig=O.TRIG_POLY)
+    oimg, _, ost = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, 320, 180, 1, 8)
+    assert (st.rays, st.box_tests, st.tri_tests) == (ost.rays, ost.box_tests, ost.tri_tests)
+    assert np.array_equal(bits(img), bits(oimg))
+    # against libm cos/sin: the stated per-pixel tolerance
+    opt.trig = O.TRIG_LIBM
+    limg, _, _ = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, 320, 180, 1, 8)
+    ok = np.all(np.abs(img - limg) <= 1e-4 + 1e-3 * np.abs(limg), axis=-1)
+    assert ok.mean() >= 0.999
+    assert psnr(img, limg) >= 45.0
+
+
+def test_progressive_equals_batched(tracer, dragon2426):
+    """sampleCount protocol: 1 spp per call for n calls == n spp in one call (same running mean)."""
+    ps, _ = dragon2426
+    tracer.upload(ps)
+    tracer.set_camera(WL.DRAGON_2426_CAMERA)
+    tracer.set_options(bounce_limit=4, seed=3)
+    whole, _, _ = tracer.trace(256, 144, 1, 6)
+    for n in range(1, 7):
+        part, _, _ = tracer.trace(256, 144, n, 1)
+    assert np.array_equal(bits(whole), bits(part))
+    a, _, _ = tracer.trace(256, 144, 1, 2)
+    b, _, _ = tracer.trace(256, 144, 3, 4)
+    assert np.array_equal(bits(whole), bits(b))
+
+
+def test_tile_split_union(tracer, dragon2426):
+    ps, _ = dragon2426
+    tracer.upload(ps)
+    tracer.set_camera(WL.DRAGON_2426_CAMERA)
+    tracer.set_options(bounce_limit=4, seed=5)
+    whole, _, st = tracer.trace(250, 141, 1, 2)  # not a multiple of the 8x8 tile
+    acc = np.zeros_like(whole)
+    rays = 0
+    for r in range(3):
+        tracer.set_options(bounce_limit=4, seed=5, tile_rank=r, tile_world=3)
+        part, _, s = tracer.trace(250, 141, 1, 2)
+        assert np.all((acc == 0) | (part == 0))
+        acc += part
+        rays += s.rays
+    assert rays == st.rays
+    assert np.array_equal(bits(whole), bits(acc))
+
+
+def test_dragon18520_small(tracer):
+    ps, os_ = product_sd_scene([WL.DRAGON_18520]), oracle_sd_scene([WL.DRAGON_18520])
+    tracer.upload(ps)
+    tracer.set_camera(WL.DRAGON_18520_CAMERA)
+    tracer.set_options(bounce_limit=8, seed=1, collect_stats=True)
+    img, prim, st = tracer.trace(240, 135, 1, 2, want_primary=True)
+    opt = O.make_options(bounce_limit=8, seed=1, trig=O.TRIG_POLY)
+    oimg, oprim, ost = os_.render(oracle_camera(WL.DRAGON_18520_CAMERA), opt, 240, 135, 1, 2, want_primary=True)
+    assert np.count_nonzero(prim != oprim) == 0
+    assert (st.rays, st.box_tests, st.tri_tests) == (ost.rays, ost.box_tests, ost.tri_tests)
+    assert np.array_equal(bits(img), bits(oimg))
+
+
+def test_errors(tracer):
+    t2 = R.Tracer(0)
+    t2.set_camera(WL.DEFAULT_CAMERA)
+    with pytest.raises(R.TracerError) as e:
+        t2.trace(64, 36)
+    assert e.value.code == -4 and "Scene is not loaded." in str(e.value)
+    with pytest.raises(R.TracerError):
+        t2.set_options(tile_rank=2, tile_world=2)
+    nodes = product_sd_scene([WL.DRAGON_2426]).nodes().copy()
+    nodes["left"][-1] = 10 ** 6
+    with pytest.raises(R.TracerError) as e:
+        t2.upload_arrays(nodes, len(nodes) - 1, product_sd_scene([WL.DRAGON_2426]).tris(), np.zeros(0), np.zeros(0), 0)
+    assert e.value.code == -5
+    t2.close()
