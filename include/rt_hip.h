@@ -108,7 +108,8 @@ typedef struct rt_options {
     int32_t tile_rank;    /* this context renders 8x8 tiles k with k % tile_world == tile_rank */
     int32_t tile_world;   /* 1 = whole image */
     int32_t collect_stats; /* also count slab / triangle / sphere tests (slower kernel variant) */
-    int32_t reserved_;
+    uint32_t sample_offset; /* added to the sample index in the RNG key only: lets several contexts each
+                               accumulate a mean over n samples of disjoint random streams (sample-range split) */
 } rt_options;
 
 typedef struct rt_stats {
@@ -117,8 +118,10 @@ typedef struct rt_stats {
     uint64_t tri_tests;
     uint64_t sph_tests;
     uint64_t tri_hits;  /* traversals that ended on a triangle */
-    float kernel_ms;    /* HIP-event time of the trace kernel on the context's stream */
-    float total_ms;     /* host wall time of the call */
+    float kernel_ms;     /* HIP-event time of the last trace kernel on the context's stream */
+    float total_ms;      /* host wall time of the call (rt_trace only) */
+    float kernel_ms_sum; /* HIP-event time summed over the launches since the previous sync */
+    uint32_t launches;   /* number of those launches */
 } rt_stats;
 
 /* Creates a context on HIP device `device`.  Stands in for the constructors of the reference's

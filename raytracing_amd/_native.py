@@ -39,12 +39,13 @@ class CameraC(C.Structure):  # rt_camera
 class OptionsC(C.Structure):  # rt_options
     _fields_ = [("bounce_limit", C.c_int32), ("estimator", C.c_int32), ("seed", C.c_uint32), ("jitter", C.c_float),
                 ("tile_rank", C.c_int32), ("tile_world", C.c_int32), ("collect_stats", C.c_int32),
-                ("reserved_", C.c_int32)]
+                ("sample_offset", C.c_uint32)]
 
 
 class StatsC(C.Structure):  # rt_stats
     _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("sph_tests", C.c_uint64),
-                ("tri_hits", C.c_uint64), ("kernel_ms", C.c_float), ("total_ms", C.c_float)]
+                ("tri_hits", C.c_uint64), ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("kernel_ms_sum", C.c_float),
+                ("launches", C.c_uint32)]
 
 
 assert C.sizeof(Node) == 36 and C.sizeof(Tri) == 100 and C.sizeof(Sphere) == 24 and C.sizeof(Material) == 24

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "rt_hip.h"
@@ -77,6 +78,7 @@ struct KParams {
     int first_sample, n_samples;
     int bounce_limit;
     uint32_t seed;
+    uint32_t sample_offset;
     float jitter;
     f3 cam_pos, bx, by, bz;
     float cam_w, cam_h, focal;
@@ -435,7 +437,7 @@ __global__ void __launch_bounds__(256) k_trace(const KParams P) {
             const f3 dir0 = basis_mul(P.bx, P.by, P.bz, view);
             const uint32_t pkey = pcg(pcg(P.seed) + pixel);
             for (int n = P.first_sample; n < P.first_sample + P.n_samples; n++) {
-                const uint32_t key = pcg(pkey + (uint32_t)n);
+                const uint32_t key = pcg(pkey + (uint32_t)n + P.sample_offset);
                 // glm::linearRand(vec3(-s), vec3(s)), Include/Random.hpp:13-16
                 const float s = P.jitter;
                 f3 jit = mk3(rng01(key, 0u) * (s - (-s)) + (-s), rng01(key, 1u) * (s - (-s)) + (-s),
@@ -490,8 +492,9 @@ struct rt_ctx {
     // work queue head and counters
     unsigned int *d_queue = nullptr;
     unsigned long long *d_counters = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    // one HIP event pair per launch since the last sync (the kernel time is read back in rt_sync)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t pending = 0;
     int num_cus = 0;
     int blocks_per_cu[4] = {0, 0, 0, 0};
 };
@@ -581,6 +584,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     P.n_samples = count;
     P.bounce_limit = o.bounce_limit;
     P.seed = o.seed;
+    P.sample_offset = o.sample_offset;
     P.jitter = o.jitter;
     // camera basis of Camera::getRayDirction (Include/Camera.hpp:40-44); it is the same for every pixel
     const rt_camera &c = ctx->cam;
@@ -608,7 +612,13 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         blocks = (waves_needed + 3) / 4;
     if (blocks < 1)
         blocks = 1;
-    RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (ctx->pending == ctx->events.size()) {
+        hipEvent_t a, b;
+        RT_HIP_CHECK(ctx, hipEventCreate(&a));
+        RT_HIP_CHECK(ctx, hipEventCreate(&b));
+        ctx->events.emplace_back(a, b);
+    }
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
     dim3 grid(blocks), block(256);
     switch (variant) {
     case 0: hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, ctx->stream, P); break;
@@ -617,8 +627,8 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     default: hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, ctx->stream, P); break;
     }
     RT_HIP_CHECK(ctx, hipGetLastError());
-    RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->timed = true;
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].second, ctx->stream));
+    ctx->pending++;
     return RT_OK;
 }
 
@@ -626,7 +636,7 @@ int sync_and_stats(rt_ctx *ctx, rt_stats *stats) {
     RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        if (ctx->timed) {
+        if (ctx->pending > 0) {
             unsigned long long h[5];
             RT_HIP_CHECK(ctx, hipMemcpy(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost));
             stats->rays = h[0];
@@ -634,11 +644,17 @@ int sync_and_stats(rt_ctx *ctx, rt_stats *stats) {
             stats->tri_tests = h[2];
             stats->sph_tests = h[3];
             stats->tri_hits = h[4];
-            float ms = 0.f;
-            RT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            float ms = 0.f, sum = 0.f;
+            for (size_t i = 0; i < ctx->pending; i++) {
+                RT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
+                sum += ms;
+            }
             stats->kernel_ms = ms;
+            stats->kernel_ms_sum = sum;
+            stats->launches = (uint32_t)ctx->pending;
         }
     }
+    ctx->pending = 0;
     return RT_OK;
 }
 
@@ -658,7 +674,7 @@ int rt_create(rt_ctx **out, int device) {
     rt_ctx *ctx = new rt_ctx();
     ctx->device = device;
     std::memset(&ctx->cam, 0, sizeof(ctx->cam));
-    ctx->opt = rt_options{4, RT_EST_SD_LOOP, 1u, 0.001f, 0, 1, 0, 0};
+    ctx->opt = rt_options{4, RT_EST_SD_LOOP, 1u, 0.001f, 0, 1, 0, 0u};
     auto bail = [&](const char *what) {
         std::fprintf(stderr, "rt_create: %s failed\n", what);
         delete ctx;
@@ -669,7 +685,6 @@ int rt_create(rt_ctx **out, int device) {
     ctx->own_stream = true;
     if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) return bail("hipMalloc");
     if (hipMalloc((void **)&ctx->d_counters, 64) != hipSuccess) return bail("hipMalloc");
-    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) return bail("hipEventCreate");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail("hipGetDeviceProperties");
     ctx->num_cus = prop.multiProcessorCount;
@@ -692,8 +707,10 @@ void rt_destroy(rt_ctx *ctx) {
     if (ctx->d_primary) (void)hipFree(ctx->d_primary);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto &e : ctx->events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -48,6 +48,7 @@ class Stats:
         self.rays, self.box_tests, self.tri_tests = c.rays, c.box_tests, c.tri_tests
         self.sph_tests, self.tri_hits = c.sph_tests, c.tri_hits
         self.kernel_ms, self.total_ms = c.kernel_ms, c.total_ms
+        self.kernel_ms_sum, self.launches = c.kernel_ms_sum, c.launches
 
     def __repr__(self):
         return (f"Stats(rays={self.rays}, box={self.box_tests}, tri={self.tri_tests}, sph={self.sph_tests}, "
@@ -91,8 +92,9 @@ class Tracer:
         self._check(N.hip().rt_set_camera(self._ctx, C.byref(c)))
 
     def set_options(self, bounce_limit=4, estimator=EST_SD_LOOP, seed=1, jitter=0.001, tile_rank=0, tile_world=1,
-                    collect_stats=False):
-        o = N.OptionsC(bounce_limit, estimator, seed, jitter, tile_rank, tile_world, 1 if collect_stats else 0, 0)
+                    collect_stats=False, sample_offset=0):
+        o = N.OptionsC(bounce_limit, estimator, seed, jitter, tile_rank, tile_world, 1 if collect_stats else 0,
+                       sample_offset)
         self._check(N.hip().rt_set_options(self._ctx, C.byref(o)))
 
     def reset(self):
