@@ -32,7 +32,7 @@ class Camera(C.Structure):
 class Options(C.Structure):
     _fields_ = [("bounce_limit", C.c_int32), ("seed", C.c_uint32), ("jitter", C.c_float), ("trig", C.c_int32),
                 ("traversal", C.c_int32), ("threads", C.c_int32), ("lock_per_pixel", C.c_int32),
-                ("accum", C.c_int32)]
+                ("accum", C.c_int32), ("tile_rank", C.c_int32), ("tile_world", C.c_int32), ("sample_offset", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -83,6 +83,9 @@ def lib():
         L.ora_old_add_mesh.argtypes = [vp, fp, C.c_uint32, C.c_uint32, fp, C.c_float]
         L.ora_old_build.argtypes = [vp]
         L.ora_old_render.argtypes = L.ora_sd_render.argtypes
+        L.ora_old_intersect.argtypes = [vp, fp, fp, C.c_int, C.POINTER(Hit)]
+        L.ora_old_flatten.argtypes = [vp, fp]
+        L.ora_old_flatten.restype = C.c_uint32
         L.ora_box_test.argtypes = [fp, fp, fp, fp, C.c_float, C.c_float]
         L.ora_rng_u32.argtypes = [C.c_uint32] * 4
         L.ora_rng_u32.restype = C.c_uint32
@@ -109,8 +112,9 @@ def make_camera(focal, position, look_at, width, aspect):
 
 
 def make_options(bounce_limit=4, seed=1, jitter=0.001, trig=TRIG_POLY, traversal=TRAV_LOOP, threads=8,
-                 lock_per_pixel=0, accum=ACCUM_RECURSIVE):
-    return Options(bounce_limit, seed, jitter, trig, traversal, threads, lock_per_pixel, accum)
+                 lock_per_pixel=0, accum=ACCUM_RECURSIVE, tile_rank=0, tile_world=1, sample_offset=0):
+    return Options(bounce_limit, seed, jitter, trig, traversal, threads, lock_per_pixel, accum, tile_rank,
+                   tile_world, sample_offset)
 
 
 def _render(fn, handle, cam, opt, width, height, first_sample, n_samples, image, want_primary):
@@ -214,6 +218,19 @@ class OldScene:
 
     def build(self):
         lib().ora_old_build(self.h)
+
+    def intersect(self, origin, direction, traversal=TRAV_LOOP):
+        o, op = _f(origin)
+        d, dp = _f(direction)
+        h = Hit()
+        lib().ora_old_intersect(self.h, op, dp, traversal, C.byref(h))
+        return h
+
+    def flatten(self):
+        n = lib().ora_old_flatten(self.h, None)
+        out = np.zeros((n, 8), dtype=np.float32)
+        lib().ora_old_flatten(self.h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
 
     def render(self, cam, opt, width, height, first_sample=1, n_samples=1, image=None, want_primary=False):
         return _render(lib().ora_old_render, self.h, cam, opt, width, height, first_sample, n_samples, image,

@@ -723,8 +723,13 @@ void renderLoop(const ora_camera &cam, const ora_options &opt, int W, int H, int
                 Counters local;
                 for (size_t y = startY; y < endY; ++y) {
                     for (size_t x = 0; x < (size_t)W; ++x) {
+                        if (opt.tile_world > 1) { // partition emulation only; the reference has no tiles
+                            size_t tile = (y / 8) * (((size_t)W + 7) / 8) + (x / 8);
+                            if ((int)(tile % (size_t)opt.tile_world) != opt.tile_rank)
+                                continue;
+                        }
                         uint32_t pixel = (uint32_t)(y * (size_t)W + x);
-                        uint32_t key = rng_key(opt.seed, pixel, (uint32_t)n);
+                        uint32_t key = rng_key(opt.seed, pixel, (uint32_t)n + opt.sample_offset);
                         float u = x / float(W), v = y / float(H); // CPUImageData::uvAt, TraceMethods.hpp:30
                         // glm::linearRand(vec3(-s), vec3(s)) : r * (max - min) + min per component
                         float s = opt.jitter;
@@ -970,6 +975,44 @@ int ora_old_render(void *s, const ora_camera *cam, const ora_options *opt, int W
         renderLoop(*cam, o, W, H, first, count, image, primary, stats,
                    [&](const Ray &ray, uint32_t key, Counters &c, uint32_t *prim) { return castRayOldRec(sc, ray, 0, o, key, c, prim); });
     return 0;
+}
+
+void ora_old_intersect(void *s, const float *o, const float *d, int traversal, ora_hit *out) {
+    OldScene &sc = *(OldScene *)s;
+    Ray ray(V3{o[0], o[1], o[2]}, V3{d[0], d[1], d[2]});
+    Counters c;
+    OldHit h = sc.intersectClosest(ray, traversal, c);
+    out->hit = h.t != kInf ? 1 : 0;
+    out->t = h.t;
+    out->pos[0] = h.pos.x; out->pos[1] = h.pos.y; out->pos[2] = h.pos.z;
+    out->normal[0] = h.normal.x; out->normal[1] = h.normal.y; out->normal[2] = h.normal.z;
+    out->prim = h.prim; out->mat = h.mat ? h.mat->kind : 0;
+    out->box_tests = (uint32_t)c.box; out->tri_tests = (uint32_t)(c.tri + c.sph);
+}
+static void flattenOld(const OldNode *n, std::vector<float> &out) {
+    if (!n)
+        return;
+    uint32_t kind = 0, ref = 0;
+    const OldMesh *mesh = nullptr;
+    if (n->object) {
+        if (dynamic_cast<const Sphere *>(n->object)) { kind = 4; ref = n->object->id & 0x3FFFFFFFu; }
+        else if ((mesh = dynamic_cast<const OldMesh *>(n->object))) { kind = 2; }
+        else { kind = 1; ref = n->object->id; }
+    }
+    float rec[8] = {n->bmin.x, n->bmin.y, n->bmin.z, n->bmax.x, n->bmax.y, n->bmax.z, bitsToFloat(kind), bitsToFloat(ref)};
+    out.insert(out.end(), rec, rec + 8);
+    if (mesh)
+        flattenOld(mesh->inside.root, out);
+    flattenOld(n->left, out);
+    flattenOld(n->right, out);
+}
+uint32_t ora_old_flatten(void *s, float *out8) {
+    OldScene &sc = *(OldScene *)s;
+    std::vector<float> v;
+    flattenOld(sc.bvh.root, v);
+    if (out8)
+        std::memcpy(out8, v.data(), v.size() * sizeof(float));
+    return (uint32_t)(v.size() / 8);
 }
 
 int ora_box_test(const float *pmin, const float *pmax, const float *o, const float *d, float tmin, float tmax) {

@@ -45,6 +45,9 @@ typedef struct ora_options {
     int32_t threads;        /* row bands, numThreads of Renderer/TraceMethods.hpp:44 */
     int32_t lock_per_pixel; /* take the shared_lock of TraceMethods.cpp:57 per pixel */
     int32_t accum;          /* ORA_ACCUM_* (old-scene path only) */
+    int32_t tile_rank;      /* render only 8x8 tiles k with k % tile_world == tile_rank ... */
+    int32_t tile_world;     /* ... (0 or 1 = whole image); mirrors rt_options for the partition tests */
+    uint32_t sample_offset; /* added to the sample index in the RNG key only */
 } ora_options;
 
 typedef struct ora_stats {
@@ -102,6 +105,12 @@ int ora_old_add_sphere(void *scene, const float *center, float radius, uint32_t 
 int ora_old_add_mesh(void *scene, const float *tris24, uint32_t n_tris, uint32_t kind, const float *albedo4,
                      float param);
 int ora_old_build(void *scene);
+void ora_old_intersect(void *scene, const float *origin, const float *dir, int traversal, ora_hit *out);
+/* Scene BVH in the order BVH::intersect visits it (node, left subtree, right subtree; a mesh leaf is
+ * followed by its inner BVH): 8 floats per node {pMin, pMax, kind bits, ref bits}, kind 0 internal,
+ * 1 triangle (ref = triangle id), 2 mesh, 4 sphere (ref = sphere index).  Returns the node count;
+ * out may be NULL to query it. */
+uint32_t ora_old_flatten(void *scene, float *out8);
 int ora_old_render(void *scene, const ora_camera *cam, const ora_options *opt, int width, int height,
                    int first_sample, int n_samples, float *image, uint32_t *primary_id, ora_stats *stats);
 
