@@ -75,17 +75,13 @@ def main():
     import raytracing_amd as R
     from raytracing_amd import workloads as WL
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    import torch.distributed as dist
+    from raytracing_amd import parallel as P
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the tracer has no CPU path")
+    rank, world, local_rank = P.init_from_env("nccl")
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -100,12 +96,11 @@ def main():
 
     def options(stats):
         tr.set_options(bounce_limit=wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
-                       collect_stats=stats, sample_offset=rank * spp)
+                       collect_stats=stats, sample_offset=P.sample_offset(rank, spp))
 
     def step():
         tr.trace_device(W, H, 1, spp, img.data_ptr())
-        if world > 1:
-            dist.reduce(img, dst=0, op=dist.ReduceOp.SUM)  # rank 0: sum of per-rank means (divide by world to average)
+        P.combine_sample_split(img, dst=0)  # N > 1: one RCCL reduce(SUM) of the per-rank means, / world on rank 0
 
     # algorithmic work of one launch: counted once, untimed, by the counting variant of the same kernel
     options(True)

@@ -1,0 +1,148 @@
+"""Host-side C++ (scene builders, OBJ reader, flat packers, plug-in layer) and the C ABI surface, on CPU.
+
+The BVH node array and triangle array the product's builders emit must be bit-identical to the
+oracle's; compute entry points are not called here (no GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import O, R, ROOT, WL, bits, objparse, oracle_old_scene, oracle_sd_scene, product_old_scene, product_sd_scene
+from raytracing_amd import _native as N
+
+
+def assert_nodes_equal(pn, on):
+    assert len(pn) == len(on)
+    for f in ("left", "right"):
+        assert np.array_equal(pn[f], on[f])
+    for f in ("pmin", "pmax"):
+        assert np.array_equal(bits(pn[f]), bits(on[f]))
+    assert np.array_equal(pn["flags"].astype(np.uint32), on["flags"])
+
+
+@pytest.mark.parametrize("paths", [[WL.DRAGON_2426], [WL.DRAGON_18520], [WL.CYLINDER], [WL.CYLINDER, WL.DRAGON_2426]])
+def test_sd_builder_bit_identical_to_oracle(paths):
+    ps, os_ = product_sd_scene(paths), oracle_sd_scene(paths)
+    assert ps.counts() == os_.counts()
+    assert_nodes_equal(ps.nodes(), os_.nodes())
+    pt, ot = ps.tris(), os_.tris()
+    for f in ("pos", "nrm", "uv"):
+        assert np.array_equal(bits(pt[f]), bits(ot[f]))
+    assert not pt["mat"].any()   # LambertianMat for every triangle (SimplifiedData.cpp:119)
+
+
+def test_sd_builder_random_soups_and_multi_mesh():
+    rng = np.random.default_rng(5)
+    for n_meshes, n in ((1, 1), (1, 2), (1, 3), (3, 40), (2, 257)):
+        tris = rng.normal(size=(n_meshes * n, 24)).astype(np.float32)
+        tris[: n] -= 5.0     # an all-negative mesh exercises the FLT_MIN quirk
+        ps = R.SdScene().add_model(tris, [n] * n_meshes).finalize()
+        os_ = O.SdScene()
+        os_.add_model(tris, [n] * n_meshes)
+        os_.finalize()
+        assert ps.counts() == os_.counts()
+        assert_nodes_equal(ps.nodes(), os_.nodes())
+
+
+def test_sd_builder_errors_match_reference_text():
+    with pytest.raises(RuntimeError, match="Build Failed. end - start <= 0"):
+        R.SdScene().finalize()
+    with pytest.raises(RuntimeError, match="Load Failed"):
+        R.SdScene().load_obj("/nonexistent/file.obj")
+
+
+def test_obj_reader_matches_independent_parser():
+    for path in (WL.CYLINDER, WL.DRAGON_2426):
+        tris, sizes = objparse.load_obj(path)
+        ps = R.SdScene().load_obj(path).finalize()
+        pt = ps.tris()
+        assert len(pt) == sum(sizes)
+        got = np.concatenate([pt["pos"], pt["nrm"], pt["uv"]], axis=2).reshape(-1, 24)
+        assert np.array_equal(bits(got), bits(tris))
+
+
+def test_flat_packers_match_oracle():
+    ps, os_ = product_sd_scene([WL.CYLINDER]), oracle_sd_scene([WL.CYLINDER])
+    (pn, pt), (on, ot) = ps.flat(), os_.flat()
+    assert np.array_equal(bits(pn), bits(on)) and np.array_equal(bits(pt), bits(ot))
+
+
+def _walk_left_first(scene):
+    nodes, out, st = scene.nodes(), [], [scene.root]
+    while st:
+        n = nodes[st.pop()]
+        kind = int(n["flags"])
+        out.append((*n["pmin"], *n["pmax"], kind, int(n["left"]) if kind in (1, 4) else 0))
+        if kind == 0:
+            st += [int(n["right"]), int(n["left"])]
+        elif kind == 2:
+            st.append(int(n["left"]))
+    return np.array(out, dtype=np.float64)
+
+
+def test_old_scene_builder_matches_oracle_tree():
+    tris, _ = objparse.load_obj(WL.CYLINDER)
+    meshes = [(tris, R.MAT_LAMBERTIAN, (0.8, 0.3, 0.3, 1.0), 0.0)]
+    for sp, ms in ((WL.small_sphere_scene(), meshes), (WL.rtiow_spheres(), ())):
+        ps, os_ = product_old_scene(sp, ms), oracle_old_scene(sp, ms)
+        mine, ref = _walk_left_first(ps), os_.flatten()
+        assert mine.shape == ref.shape
+        assert np.array_equal(bits(mine[:, :6].astype(np.float32)), bits(ref[:, :6]))
+        assert np.array_equal(mine[:, 6].astype(np.uint32), ref[:, 6].view(np.uint32))
+        assert np.array_equal(mine[:, 7].astype(np.uint32), ref[:, 7].view(np.uint32))
+    assert len(WL.rtiow_spheres()) == 485
+    s = product_old_scene(WL.small_sphere_scene())
+    assert list(s.spheres()["prim_id"]) == [0x40000000 + i for i in range(5)]
+    assert list(s.materials()["kind"]) == [0, 4, 0, 1, 2]
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char \*)\s*\*?(rt_[a-z_]+)\(", hdr, re.M))
+    assert declared == set(N.HIP_SYMBOLS), declared ^ set(N.HIP_SYMBOLS)
+    lib = N.hip()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.rt_version().decode().endswith("gfx950")
+    assert C.sizeof(N.Node) == 36 and C.sizeof(N.Tri) == 100          # == sizeof(sd::Node), sizeof(sd::Triangle)
+    assert N.Node.flags.offset == 32 and N.Tri.mat.offset == 96
+    assert C.sizeof(N.CameraC) == 40 and C.sizeof(N.OptionsC) == 32 and C.sizeof(N.StatsC) == 56
+
+
+def test_kernels_are_compiled_for_gfx950_without_fma_contraction():
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    out = subprocess.run([objdump, "--offloading", N.HIP_LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    ctx = C.c_void_p()
+    assert N.hip().rt_create(C.byref(ctx), 0) == -2 and not ctx.value   # RT_ERR_NO_DEVICE
+    with pytest.raises(R.TracerError):
+        R.Tracer(0)
+    with pytest.raises(RuntimeError, match="no usable HIP device"):
+        R.PluginHarness(R.PluginHarness.MODE_SD, 64, 36, WL.DEFAULT_CAMERA)
+    assert N.hip().rt_trace(None, 1, 1, 1, 1, None, None, None) == -1        # null context: invalid argument
+    assert N.hip().rt_last_error(None) == b"null context"
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped package and the native sources never import, include or link the oracle."""
+    pkg = os.path.join(ROOT, "raytracing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+    import subprocess
+    for lib in (N.HIP_LIB_PATH, N.HOST_LIB_PATH):
+        deps = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
+        assert "oracle" not in deps

@@ -1,0 +1,272 @@
+"""Known-answer and self-consistency tests that pin the CPU oracle (CPU only).
+
+The reference has no tests for this path, so these stand in for them: hand-computable cases for every
+primitive of the path, the reference's own debugging aids turned into checks (recursive vs loop
+traversal, BVH vs brute force, flat pack/unpack round trip) and its one literal data dump as a layout
+check.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, O, WL, bits, objparse, oracle_camera, oracle_old_scene, oracle_sd_scene
+
+F32 = np.float32
+
+
+def tri24(p0, p1, p2, n=(0, 0, 1)):
+    return np.array([*p0, *n, 0, 0, *p1, *n, 1, 0, *p2, *n, 0, 1], dtype=np.float32)
+
+
+def one_tri_scene(*tris):
+    s = O.SdScene()
+    s.add_model(np.stack(tris))
+    s.finalize()
+    return s
+
+
+# ---- Moller-Trumbore, SimplifiedData.cpp:269-307 --------------------------------------------------
+def test_axis_aligned_ray_unit_triangle():
+    s = one_tri_scene(tri24((0, 0, 0), (1, 0, 0), (0, 1, 0)))
+    h = s.intersect((0.25, 0.25, 1.0), (0, 0, -1))
+    assert h.hit == 1 and h.t == 1.0 and h.prim == 0
+    assert list(h.pos) == [0.25, 0.25, 0.0] and list(h.normal) == [0.0, 0.0, 1.0]
+    assert s.intersect((0.75, 0.75, 1.0), (0, 0, -1)).hit == 0          # u + v > 1
+    assert s.intersect((0.25, 0.25, -1.0), (0, 0, -1)).hit == 0         # behind the origin (t < EPS)
+    assert s.intersect((0.25, 0.25, -1.0), (0, 0, 1)).hit == 1          # two-sided: no back-face culling
+    assert s.intersect((0.25, 0.25, 1.0), (1, 0, 0)).hit == 0           # parallel: |a| < 1e-7
+    # direction is not normalised by the tracer: t scales with 1/|d|
+    assert s.intersect((0.25, 0.25, 1.0), (0, 0, -4)).t == 0.25
+
+
+def test_triangle_edges_are_inclusive():
+    s = one_tri_scene(tri24((0, 0, 0), (1, 0, 0), (0, 1, 0)))
+    assert s.intersect((0.0, 0.5, 1.0), (0, 0, -1)).hit == 1   # u == 0
+    assert s.intersect((0.5, 0.5, 1.0), (0, 0, -1)).hit == 1   # u + v == 1
+
+
+# ---- slab test, SimplifiedData.cpp:146-161 ----------------------------------------------------------
+def test_slab_zero_direction_component_inf_nan_path():
+    lo, hi = (0, 0, 0), (1, 1, 1)
+    assert O.box_test(lo, hi, (0.5, 0.5, -1), (0, 0, 1), 1e-6, np.inf)       # invD = (inf, inf, 1)
+    assert not O.box_test(lo, hi, (2.0, 0.5, -1), (0, 0, 1), 1e-6, np.inf)   # outside on a zero axis
+    # origin exactly on a slab plane of a zero axis: (0 - 0) * inf = NaN falls through both selects
+    assert O.box_test(lo, hi, (0.0, 0.5, -1), (0, 0, 1), 1e-6, np.inf)
+    assert not O.box_test(lo, hi, (0.5, 0.5, -1), (0, 0, 1), 1e-6, 1.0)       # tMax <= tMin rejects (box starts at t = 1)
+    assert O.box_test(lo, hi, (0.5, 0.5, -1), (0, 0, 1), 1e-6, 1.0000001)
+    assert not O.box_test(lo, hi, (0.5, 0.5, 2), (0, 0, 1), 1e-6, np.inf)    # box behind the ray
+    assert O.box_test(lo, hi, (0.5, 0.5, 0.5), (0, 0, 1), 1e-6, np.inf)      # origin inside
+
+
+# ---- BVH build quirks, SimplifiedData.cpp:322-399 ---------------------------------------------------
+def test_flt_min_pmax_quirk_on_all_negative_extent():
+    """Three or more children start from BoundingBox{FLT_MAX, FLT_MIN}; FLT_MIN is +1.18e-38, so a
+    wholly negative extent is clamped up to ~0 (SimplifiedData.hpp:64-69)."""
+    tris = [tri24((-3 - i, -2, -5), (-2.5 - i, -2, -5), (-3 - i, -1.5, -5.5)) for i in range(3)]
+    s = one_tri_scene(*tris)
+    nodes = s.nodes()
+    assert s.counts() == (5, 3, 4)
+    root = nodes[4]
+    assert np.all(root["pmax"] == np.float32(1.17549435e-38))
+    assert np.all(root["pmin"] < -1.0)
+    # the two-child node keeps the plain union
+    two = nodes[3]
+    assert np.all(two["pmax"] < 0)
+    # leaves first in face order, children emitted before parents, root last
+    assert list(nodes["flags"]) == [1, 1, 1, 0, 0]
+    assert [int(x) for x in nodes["left"][:3]] == [0, 1, 2]
+    assert int(root["left"]) in (0, 1, 2) and int(root["right"]) == 3   # mid = 1: one leaf left, two right
+
+
+def test_split_axis_and_median():
+    # 4 triangles spread along y: sorted by pMin.y + pMax.y, split 2 | 2
+    tris = [tri24((0, y, 1), (0.1, y, 1), (0, y + 0.1, 1)) for y in (3.0, 1.0, 4.0, 2.0)]
+    s = one_tri_scene(*tris)
+    n = s.nodes()
+    assert s.counts() == (7, 4, 6)
+    left, right = n[int(n[6]["left"])], n[int(n[6]["right"])]
+    assert sorted([int(left["left"]), int(left["right"])]) == [1, 3]    # y = 1, 2
+    assert sorted([int(right["left"]), int(right["right"])]) == [0, 2]  # y = 3, 4
+    assert np.allclose(n[0]["pmin"], [0 - 1e-5, 3 - 1e-5, 1 - 1e-5])    # leaf box = corners +- 1e-5
+
+
+def test_single_mesh_roots_pass_through():
+    s = oracle_sd_scene([WL.DRAGON_2426])
+    assert s.counts() == (4851, 2426, 4850)
+
+
+# ---- traversal self-checks ---------------------------------------------------------------------------
+@pytest.mark.parametrize("path,cam", [(WL.DRAGON_2426, WL.DRAGON_2426_CAMERA), (WL.CYLINDER, WL.DEFAULT_CAMERA)])
+def test_loop_vs_recursive_vs_brute(path, cam):
+    s = oracle_sd_scene([path])
+    opt = O.make_options(bounce_limit=3, seed=11, trig=O.TRIG_POLY)
+    img, prim, st = s.render(oracle_camera(cam), opt, 160, 90, 1, 1, want_primary=True)
+    assert (prim != O.MISS).sum() > 100
+    for trav in (O.TRAV_RECURSIVE, O.TRAV_BRUTE):
+        opt.traversal = trav
+        img2, prim2, st2 = s.render(oracle_camera(cam), opt, 160, 90, 1, 1, want_primary=True)
+        # visiting order differs (right-first loop, left-first recursion, storage order), so exact-t ties
+        # may resolve to another triangle; everything else must be identical
+        assert (prim != prim2).mean() < 1e-3
+        assert np.abs(img - img2).max() < 0.5 and (np.abs(img - img2) > 0).mean() < 1e-2
+        assert st2.rays >= 160 * 90
+
+
+def test_flat_pack_unpack_roundtrip():
+    s = oracle_sd_scene([WL.CYLINDER])
+    fn, ft = s.flat()
+    nodes, tris = s.nodes(), s.tris()
+    assert fn.shape == (len(nodes), 9) and ft.shape == (len(tris), 25)
+    for i in (0, 5, len(nodes) - 1):
+        back = O.unpack_flat_node(fn, i)
+        assert back.tobytes() == nodes[i].tobytes()
+    back = O.unpack_flat_tri(ft, 3)
+    assert np.array_equal(back["pos"], tris[3]["pos"]) and np.array_equal(back["nrm"], tris[3]["nrm"])
+    # indices and flags are bit-punned, not converted: leaf flag 1 reads as the denormal 1.4013e-45
+    assert fn[0, 8] == np.float32(1.4013e-45) and fn[-1, 8] == 0.0
+    # known quirk of GetTriangleFromFlatStorage (SimplifiedData.cpp:252): the material word is converted by
+    # VALUE, so a bit-punned small integer always reads back as 0
+    ft2 = ft.copy()
+    ft2[3, 24] = np.array([2], dtype=np.uint32).view(np.float32)[0]
+    assert O.unpack_flat_tri(ft2, 3)["mat"] == 0
+
+
+def test_layout_matches_reference_dump():
+    with open(os.path.join(GOLDEN, "testscene_glsl.json")) as fh:
+        ref = json.load(fh)
+    t = np.array(ref["triangles"], dtype=np.float32)
+    s = O.SdScene()
+    s.add_model(t[:, :24])
+    s.finalize()
+    fn, ft = s.flat()
+    n, _, root = s.counts()
+    assert (n, root) == (3, ref["root"])
+    dump = np.array(ref["nodes"], dtype=np.float32)
+    assert np.array_equal(bits(fn[:, [0, 1, 8]]), bits(dump[:, [0, 1, 8]]))   # child indices and flags, bit-punned
+    assert np.allclose(fn[:, 2:8], dump[:, 2:8], atol=2e-5)                  # boxes (dump used a 1e-6 bias, 6 digits)
+    assert np.allclose(ft, t, atol=1e-6)
+
+
+# ---- sphere, Objects.hpp:43-72 -------------------------------------------------------------------------
+def test_sphere_near_root_inside_miss_and_dielectric_exit():
+    lam = oracle_old_scene([((0, 0, 0), 1.0, O.MAT_LAMBERTIAN, (1, 1, 1, 1), 0.0)])
+    h = lam.intersect((0, 0, 3), (0, 0, -1))
+    assert h.hit == 1 and h.t == 2.0 and list(h.normal) == [0.0, 0.0, 1.0] and h.prim == 0x40000000
+    assert lam.intersect((0, 0, 3), (0, 0, -2)).t == 1.0           # un-normalised direction
+    assert lam.intersect((0, 0, 0), (0, 0, -1)).hit == 0            # origin inside: near root < 0 -> miss
+    assert lam.intersect((0, 0, 3), (0, 0, 1)).hit == 0             # behind
+    assert lam.intersect((0, 2, 3), (0, 0, -1)).hit == 0            # discriminant < 0
+    glass = oracle_old_scene([((0, 0, 0), 1.0, O.MAT_DIELECTRIC, (1, 1, 1, 1), 1.5)])
+    h = glass.intersect((0, 0, 0), (0, 0, -1))                      # this build's addition: the exit point
+    assert h.hit == 1 and h.t == 1.0 and list(h.normal) == [0.0, 0.0, -1.0]
+
+
+def test_old_bvh_zero_box_quirk():
+    """BVH::BuildBVH starts the union of >= 3 boxes from a value-initialised (all-zero) node
+    (BVH.hpp:42-47), so such a node always contains the origin."""
+    sp = [((10 + 3 * i, 10, 10), 1.0, O.MAT_LAMBERTIAN, (1, 1, 1, 1), 0.0) for i in range(3)]
+    flat = oracle_old_scene(sp).flatten()
+    assert np.all(flat[0, :3] == 0.0) and list(flat[0, 3:6]) == [17.0, 11.0, 11.0]
+    kinds = flat[:, 6].view(np.uint32)
+    assert list(kinds) == [0, 4, 0, 4, 4]   # root, left leaf, right pair node, its two leaves
+
+
+# ---- camera, RNG, sampling ----------------------------------------------------------------------------
+def test_camera_center_ray_and_flip():
+    cam = oracle_camera(WL.DEFAULT_CAMERA)
+    assert list(O.camera_dir(cam, 0.5, 0.5)) == [0.0, 0.0, -1.0]
+    d = O.camera_dir(cam, 0.0, 0.0)   # pixel (0,0) is the bottom-left corner: x to the left, y down
+    assert d[0] < 0 and d[1] < 0 and d[2] < 0
+    assert abs(float(np.linalg.norm(d)) - 1.0) < 1e-6
+    assert np.isclose(d[0] / d[2], 1.0, rtol=1e-6) and np.isclose(d[1] / d[2], 0.5625, rtol=1e-6)
+
+
+def _pcg(v):
+    v &= 0xFFFFFFFF
+    s = (v * 747796405 + 2891336453) & 0xFFFFFFFF
+    w = (((s >> ((s >> 28) + 4)) ^ s) * 277803737) & 0xFFFFFFFF
+    return ((w >> 22) ^ w) & 0xFFFFFFFF
+
+
+def test_counter_rng_definition():
+    for seed, pixel, sample, dim in [(1, 0, 1, 0), (42, 123456, 7, 5), (0xFFFFFFFF, 2073599, 1024, 35)]:
+        key = _pcg(_pcg(_pcg(seed) + pixel) + sample)
+        assert O.rng_u32(seed, pixel, sample, dim) == _pcg(key + dim * 0x9E3779B9)
+    vals = np.array([O.rng_u32(1, p, 1, 4) >> 8 for p in range(4096)]) / 16777216.0
+    assert 0.47 < vals.mean() < 0.53 and vals.min() >= 0.0 and vals.max() < 1.0
+
+
+def test_polynomial_sincos_within_2ulp():
+    th = np.linspace(0.0, 6.2831855, 20001, dtype=np.float32)
+    worst = 0.0
+    for t in th[::7]:
+        s, c = O.sincos(float(t), O.TRIG_POLY)
+        es, ec = np.sin(np.float64(t)), np.cos(np.float64(t))
+        for got, exp in ((s, es), (c, ec)):
+            ulp = np.spacing(np.float32(max(abs(exp), 2.0 ** -20)))
+            worst = max(worst, abs(got - exp) / ulp)
+    assert worst <= 2.0
+    s, c = O.sincos(0.0, O.TRIG_POLY)
+    assert (s, c) == (0.0, 1.0)
+
+
+def test_cosine_direction_is_unit_and_in_hemisphere():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n = rng.normal(size=3)
+        n = (n / np.linalg.norm(n)).astype(np.float32)
+        u1, u2 = rng.random(2)
+        for trig in (O.TRIG_LIBM, O.TRIG_POLY):
+            d = O.cosine_dir(n, float(u1), float(u2), trig)
+            assert abs(float(np.linalg.norm(d)) - 1.0) < 1e-5
+            assert float(np.dot(d, n)) >= -1e-6
+        a, b = O.cosine_dir(n, float(u1), float(u2), 0), O.cosine_dir(n, float(u1), float(u2), 1)
+        assert np.abs(a - b).max() < 1e-6
+    assert list(O.cosine_dir((0, 0, 1), 0.0, 0.0, O.TRIG_POLY)) == [0.0, 0.0, 1.0]
+
+
+# ---- estimators -----------------------------------------------------------------------------------------
+def test_sd_estimator_sky_and_alpha():
+    s = one_tri_scene(tri24((100, 100, 100), (101, 100, 100), (100, 101, 100)))   # out of view
+    cam = oracle_camera(WL.DEFAULT_CAMERA)
+    img, _, st = s.render(cam, O.make_options(bounce_limit=4, jitter=0.0), 16, 9, 1, 1)
+    assert st.rays == 16 * 9 and np.all(img[..., 3] == 1.0)
+    d = O.camera_dir(cam, 0.5, 0.0)
+    a = np.float32(0.5) * (d[1] / np.float32(np.linalg.norm(d.astype(np.float64))) + np.float32(1.0))
+    exp = (1 - a) * np.array([1, 1, 1], np.float32) + a * np.array([0.5, 0.7, 1.0], np.float32)
+    assert np.allclose(img[0, 8, :3], exp, atol=1e-6)
+    # bounce limit 0: no traversal at all, colour and alpha stay 0 (Trace.cpp:63)
+    img0, _, st0 = s.render(cam, O.make_options(bounce_limit=0), 16, 9, 1, 1)
+    assert st0.rays == 0 and not img0.any()
+
+
+def test_running_mean_protocol():
+    s = oracle_sd_scene([WL.CYLINDER])
+    cam = oracle_camera(WL.DEFAULT_CAMERA)
+    opt = O.make_options(bounce_limit=4, seed=3)
+    whole, _, _ = s.render(cam, opt, 48, 27, 1, 5)
+    img = None
+    for n in range(1, 6):
+        img, _, _ = s.render(cam, opt, 48, 27, n, 1, image=img)
+    assert np.array_equal(bits(whole), bits(img))
+    assert ((whole[..., 3] >= 0) & (whole[..., 3] <= 1)).all()   # alpha = fraction of samples that reached the sky
+
+
+def test_recursive_and_forward_products_agree():
+    sc = oracle_old_scene(WL.small_sphere_scene())
+    cam = O.make_camera(3.19, (13.0, 2.0, 3.0), (0.0, 0.5, 0.0), 2.0, 16 / 9)
+    a, _, sa = sc.render(cam, O.make_options(bounce_limit=8, accum=O.ACCUM_RECURSIVE), 96, 54, 1, 4)
+    b, _, sb = sc.render(cam, O.make_options(bounce_limit=8, accum=O.ACCUM_FORWARD), 96, 54, 1, 4)
+    assert sa.rays == sb.rays and np.allclose(a, b, rtol=1e-6, atol=1e-7)
+    # roulette: depth <= 1 never terminates, so every pixel has at least its camera ray
+    assert sa.rays >= 96 * 54 * 4
+
+
+def test_obj_fan_triangulation_counts():
+    tris, sizes = objparse.load_obj(WL.CYLINDER)
+    assert sizes == [124] and tris.shape == (124, 24)      # 32 quads + two 32-gons
+    tris, sizes = objparse.load_obj(WL.DRAGON_18520)
+    assert sizes == [18520]
+    assert np.all(tris.reshape(-1, 3, 8)[:, :, 6:] == 0)    # no vt in the file -> uv = 0
