@@ -100,6 +100,15 @@ enum {
     RT_ORDER_LEFT_FIRST = 1   /* BVH::intersect / sd::BVH::Intersect recurse left first, BVH.hpp:143-144 */
 };
 
+/* How a wave walks the node array.  Every choice performs, per ray, exactly the reference's slab and
+ * primitive tests in the reference's order; they differ only in how node records are fetched. */
+enum {
+    RT_TRAV_AUTO = 0,
+    RT_TRAV_LANE = 1,  /* every lane follows its own index; node records through the vector memory path */
+    RT_TRAV_WAVE = 2,  /* the wave advances together; node records through the scalar data path */
+    RT_TRAV_NESTED = 3 /* first-generation kernel: one 8x8 tile per wave, nested sample/bounce loops, per-lane walk */
+};
+
 typedef struct rt_options {
     int32_t bounce_limit; /* Trace::bounceLimit, CPURayTrace/Trace.hpp:16 */
     int32_t estimator;    /* RT_EST_* */
@@ -110,6 +119,7 @@ typedef struct rt_options {
     int32_t collect_stats; /* also count slab / triangle / sphere tests (slower kernel variant) */
     uint32_t sample_offset; /* added to the sample index in the RNG key only: lets several contexts each
                                accumulate a mean over n samples of disjoint random streams (sample-range split) */
+    int32_t traversal;      /* RT_TRAV_* */
 } rt_options;
 
 typedef struct rt_stats {

@@ -39,7 +39,7 @@ class CameraC(C.Structure):  # rt_camera
 class OptionsC(C.Structure):  # rt_options
     _fields_ = [("bounce_limit", C.c_int32), ("estimator", C.c_int32), ("seed", C.c_uint32), ("jitter", C.c_float),
                 ("tile_rank", C.c_int32), ("tile_world", C.c_int32), ("collect_stats", C.c_int32),
-                ("sample_offset", C.c_uint32)]
+                ("sample_offset", C.c_uint32), ("traversal", C.c_int32)]
 
 
 class StatsC(C.Structure):  # rt_stats

@@ -59,6 +59,9 @@ RT_HD f3 basis_mul(f3 c0, f3 c1, f3 c2, f3 v) {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kSphereBit = 0x80000000u;
 constexpr uint32_t KIND_INTERNAL = 0, KIND_TRI = 1, KIND_MESH = 2, KIND_SPHERE = 4;
+constexpr int kMaxLevels = 64;             // bounce levels a wavefront trace can launch (bounce_limit <= 62)
+constexpr int kChunkSamples = 16;          // samples per pixel traced per wavefront chunk
+constexpr size_t kMaxItems = 48u << 20;    // work items (pixel samples) per chunk: bounds the queue workspace
 
 // ------------------------------------------------------------------ kernel parameters
 struct KParams {
@@ -79,6 +82,17 @@ struct KParams {
     int bounce_limit;
     uint32_t seed;
     uint32_t sample_offset;
+    int wave_sync;
+    // wavefront launches (k_path)
+    const float4 *q_in;         // path records of this level (4 x float4 each)
+    float4 *q_out;              // path records of the next level
+    float4 *colors;             // colors[sample in chunk][pixel]
+    unsigned int *cursor;       // work cursor of this level
+    const unsigned int *n_in;   // record count of this level (levels > 0)
+    unsigned int *n_out;        // append counter of the next level
+    uint32_t n_items;           // level 0: n_my_tiles * 64 * S
+    uint32_t npix;
+    int level, S, chunk_first;
     float jitter;
     f3 cam_pos, bx, by, bz;
     float cam_w, cam_h, focal;
@@ -469,6 +483,415 @@ __global__ void __launch_bounds__(256) k_trace(const KParams P) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wave-synchronous closest hit.  All lanes of the wave walk the node array together: the wave visits
+// index `cur` when at least one lane's own traversal would visit it.  A lane that fails the slab test
+// of an internal node parks until `cur` reaches that node's skip index (`resume`); because subtrees
+// are nested intervals of the array, no parked lane can want a node before the skip index of a node
+// every active lane has just failed, so the wave's next index is simply cur+1 or skip.  Each lane
+// therefore performs exactly the tests of its own reference traversal, in the same order, with its
+// own running closest distance -- but the node (and triangle / sphere) record is fetched ONCE per
+// wave through the scalar data path into SGPRs instead of 64 times through the vector memory path.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const v4f __attribute__((address_space(4))) *cf4ptr; // constant address space: scalar loads
+
+template <bool OLD, bool STATS>
+RT_D void closest_hit_wave(const KParams &P, const bool live, const f3 o, const f3 d, const f3 inv, Best &best,
+                           Cnt &cnt) {
+    typedef const char __attribute__((address_space(4))) *cbytes;
+    const cbytes nodes = (cbytes)(uintptr_t)P.nodes;
+    const cf4ptr tri_pos = (cf4ptr)(uintptr_t)P.tri_pos;
+    const cf4ptr spheres = (cf4ptr)(uintptr_t)P.spheres;
+    best.t = __builtin_inff();
+    best.u = 0.0f;
+    best.v = 0.0f;
+    best.ref = kNone;
+    Best outer = best;
+    uint32_t inner_end = kNone;
+    uint32_t resume = live ? 0u : kNone;
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const uint32_t n = P.n_nodes;
+    uint32_t cur = 0;
+    while (cur < n) {
+        const v4f a = *(cf4ptr)(nodes + cur * 32u), b = *(cf4ptr)(nodes + cur * 32u + 16u);
+        const uint32_t skip = __float_as_uint(b.z);
+        const uint32_t kind = __float_as_uint(b.w);
+        const float dx0 = a.x - o.x, dx1 = a.w - o.x, dy0 = a.y - o.y, dy1 = b.x - o.y, dz0 = a.z - o.z, dz1 = b.y - o.z;
+        const bool act = resume <= cur;
+        if (OLD) {
+            if (act && cur == inner_end) {
+                if (!(best.t < outer.t))
+                    best = outer;
+                inner_end = kNone;
+            }
+        }
+        if (STATS)
+            cnt.box += act ? 1ull : 0ull;
+        float t0x = dx0 * inv.x, t1x = dx1 * inv.x;
+        float t0y = dy0 * inv.y, t1y = dy1 * inv.y;
+        float t0z = dz0 * inv.z, t1z = dz1 * inv.z;
+        float nearx = nx ? t1x : t0x, farx = nx ? t0x : t1x;
+        float neary = ny ? t1y : t0y, fary = ny ? t0y : t1y;
+        float nearz = nz ? t1z : t0z, farz = nz ? t0z : t1z;
+        float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+        float tmax = fminf(farz, fminf(fary, fminf(farx, best.t)));
+        const bool pass = act && !(tmax <= tmin);
+        if (act && !pass)
+            resume = skip;
+        const bool any = __builtin_amdgcn_ballot_w64(pass) != 0ull;
+        const uint32_t k = kind & 7u;
+        const uint32_t slot = kind >> 3;
+        uint32_t next = cur + 1; // == skip for every leaf kind except a mesh leaf nobody entered
+        if (k == KIND_INTERNAL) {
+            next = any ? cur + 1 : skip;
+        } else if (!any) {
+            if (OLD && k == KIND_MESH)
+                next = skip;
+        } else if (k == KIND_TRI) {
+            const v4f q0 = tri_pos[3 * slot], q1 = tri_pos[3 * slot + 1], q2 = tri_pos[3 * slot + 2];
+            if (pass) {
+                if (STATS)
+                    cnt.tri++;
+                const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+                const float EPSILON = 1e-7f;
+                f3 h = cross3(d, e2);
+                float det = dot3(e1, h);
+                if (!(det > -EPSILON && det < EPSILON)) {
+                    float f = 1.0f / det;
+                    f3 sv = o - p0;
+                    float u = f * dot3(sv, h);
+                    if (!(u < 0.0f || u > 1.0f)) {
+                        f3 q = cross3(sv, e1);
+                        float v = f * dot3(d, q);
+                        if (!(v < 0.0f || u + v > 1.0f)) {
+                            float t = f * dot3(e2, q);
+                            if (t > EPSILON && t < best.t) {
+                                best.t = t;
+                                best.u = u;
+                                best.v = v;
+                                best.ref = slot;
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (OLD && k == KIND_SPHERE) {
+            const v4f s0 = spheres[2 * slot], s1 = spheres[2 * slot + 1];
+            if (pass) {
+                if (STATS)
+                    cnt.sph++;
+                f3 oc = mk3(s0.x, s0.y, s0.z) - o;
+                float qa = dot3(d, d);
+                float qb = -2.0f * dot3(d, oc);
+                float qc = dot3(oc, oc) - s0.w * s0.w;
+                float disc = qb * qb - 4 * qa * qc;
+                if (!(disc < 0)) {
+                    float t = (-qb - sqrtf(disc)) / (2.0f * qa);
+                    bool ok = !(t < 0);
+                    if (!ok && __float_as_uint(s1.z) != 0u) {
+                        t = (-qb + sqrtf(disc)) / (2.0f * qa);
+                        ok = !(t < 0);
+                    }
+                    if (ok && t < best.t) {
+                        best.t = t;
+                        best.ref = kSphereBit | slot;
+                    }
+                }
+            }
+        } else if (OLD && k == KIND_MESH) {
+            if (pass) {
+                outer = best;
+                inner_end = skip;
+                best.t = __builtin_inff();
+                best.ref = kNone;
+            }
+        }
+        cur = __builtin_amdgcn_readfirstlane(next);
+    }
+    if (OLD) {
+        if (live && inner_end != kNone) {
+            if (!(best.t < outer.t))
+                best = outer;
+        }
+    }
+}
+
+// Path state carried from one bounce level to the next.
+struct Path {
+    f3 o, d, inv; // current ray
+    float4 thr;   // throughput (w used by the old-scene estimator only)
+    float rr;     // old-scene estimator: roulette weight of the current depth
+    int depth;    // traversals already started on this path
+    uint32_t key; // RNG key of (pixel, sample)
+};
+
+// Wavefront path kernel: one launch per bounce level.
+//
+// Level 0 generates the camera rays of `S` consecutive samples of every pixel this context owns.  A
+// wave takes 64 work items at a time from an atomic cursor; items are numbered (tile, sample, pixel in
+// the 8x8 tile), so the 64 rays of a batch are the camera rays of one tile for one sample and stay
+// coherent.  After the closest-hit search a path either ENDS -- its colour is stored in the per-sample
+// colour buffer, colors[sample][pixel] -- or CONTINUES: its state is appended to the queue of the next
+// level, which the next launch consumes 64 records per wave.  Paths of every depth therefore run in
+// full waves, and no lane ever waits for a neighbour's longer path.  The per-sample colours are folded
+// into the running mean afterwards, in sample order, by k_fold, which reproduces the reference's
+// "pixel = (pixel*(n-1) + new)/n" (Renderer/TraceMethods.cpp:59) bit for bit.
+template <bool OLD, bool STATS>
+__global__ void __launch_bounds__(256) k_path(const KParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull};
+    const uint32_t n_in = P.level == 0 ? P.n_items : *P.n_in;
+    for (;;) {
+        unsigned int base = 0;
+        if (lane == 0)
+            base = atomicAdd(P.cursor, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n_in)
+            break;
+        const uint32_t g = base + lane;
+        bool live = g < n_in;
+        Path path;
+        uint32_t cidx = 0;
+        if (P.level == 0) {
+            const uint32_t per_tile = 64u * (uint32_t)P.S;
+            const uint32_t j = base / per_tile;
+            const uint32_t s = (base - j * per_tile) >> 6;
+            const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
+            const int x = (int)(tile % (uint32_t)P.tiles_x) * 8 + (int)(lane & 7u);
+            const int y = (int)(tile / (uint32_t)P.tiles_x) * 8 + (int)(lane >> 3);
+            live = live && x < P.W && y < P.H;
+            const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+            const int n = P.chunk_first + (int)s;
+            cidx = s * P.npix + pixel;
+            // CPUImageData::uvAt, Renderer/TraceMethods.hpp:30; Camera::getRayDirction, Camera.hpp:33-47
+            const float u = (float)x / (float)P.W, v = (float)y / (float)P.H;
+            f3 view = normalize3(mk3(u * P.cam_w - P.cam_w / 2, v * P.cam_h - P.cam_h / 2, P.focal));
+            view.x = -view.x;
+            const f3 dir0 = basis_mul(P.bx, P.by, P.bz, view);
+            path.key = pcg(pcg(pcg(P.seed) + pixel) + (uint32_t)n + P.sample_offset);
+            // glm::linearRand(vec3(-s), vec3(s)), Include/Random.hpp:13-16
+            const float js = P.jitter;
+            f3 jit = mk3(rng01(path.key, 0u) * (js - (-js)) + (-js), rng01(path.key, 1u) * (js - (-js)) + (-js),
+                         rng01(path.key, 2u) * (js - (-js)) + (-js));
+            path.o = P.cam_pos;
+            path.d = dir0 + jit;
+            path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
+            path.rr = 1.0f;
+            path.depth = 0;
+            if (!OLD && P.bounce_limit <= 0) { // Trace.cpp:63: no traversal at all, the sample is (0,0,0,0)
+                if (live) {
+                    P.colors[cidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (P.primary != nullptr && n == P.first_sample)
+                        P.primary[pixel] = kNone;
+                }
+                live = false;
+            }
+        } else {
+            path.o = path.d = mk3(1.f, 1.f, 1.f);
+            path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
+            path.rr = 1.0f;
+            path.depth = 0;
+            path.key = 0;
+            if (live) {
+                const float4 r0 = P.q_in[4 * (size_t)g], r1 = P.q_in[4 * (size_t)g + 1], r2 = P.q_in[4 * (size_t)g + 2],
+                             r3 = P.q_in[4 * (size_t)g + 3];
+                path.o = mk3(r0.x, r0.y, r0.z);
+                path.d = mk3(r0.w, r1.x, r1.y);
+                path.thr = make_float4(r1.z, r1.w, r2.x, r2.y);
+                path.rr = r2.z;
+                path.key = __float_as_uint(r2.w);
+                cidx = __float_as_uint(r3.x);
+                path.depth = (int)__float_as_uint(r3.y);
+            }
+        }
+        if (__ballot(live) == 0ull)
+            continue;
+        path.inv = mk3(1.0f / path.d.x, 1.0f / path.d.y, 1.0f / path.d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
+        // ---- one closest-hit search per lane ----
+        Best hit;
+        if (live)
+            cnt.rays++;
+        if (P.wave_sync) {
+            closest_hit_wave<OLD, STATS>(P, live, path.o, path.d, path.inv, hit, cnt);
+        } else {
+            hit.ref = kNone;
+            hit.t = 0.f;
+            hit.u = hit.v = 0.f;
+            if (live)
+                closest_hit<OLD, STATS>(P, path.o, path.d, path.inv, hit, cnt);
+        }
+        // ---- shade: the path ends with a colour or continues with a new ray ----
+        bool ended = false;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            const uint32_t dim = 3u + 4u * (uint32_t)path.depth;
+            const bool first = path.depth == 0;
+            path.depth++;
+            uint32_t prim = kNone;
+            if (!OLD) { // Trace::CastRay(ray, depth, sd::DataStorage&), CPURayTrace/Trace.cpp:58-96
+                if (hit.ref != kNone) {
+                    if (STATS)
+                        cnt.trih++;
+                    const float4 q2 = P.tri_pos[3 * hit.ref + 2];
+                    prim = __float_as_uint(q2.y);
+                    if (__float_as_uint(q2.z) == 0u) { // LambertianMat; otherwise the same ray is cast again (Trace.cpp:80-82)
+                        f3 N = tri_normal(P, hit.ref, hit.u, hit.v);
+                        f3 pos = path.o + hit.t * path.d;
+                        f3 bias = N * 1e-5f; // Lambertian::Hit, Materials/Lambertian.hpp:35-48
+                        float u1 = rng01(path.key, dim + 1u);
+                        float u2 = rng01(path.key, dim + 2u);
+                        path.d = cosine_dir(N, u1, u2);
+                        path.o = pos + bias;
+                        path.thr = make_float4(path.thr.x * 0.9f, path.thr.y * 0.6f, path.thr.z * 0.5f, 1.f);
+                    }
+                    ended = !(path.depth < P.bounce_limit); // loop condition of Trace.cpp:63: colour stays (0,0,0,0)
+                } else {
+                    f3 sk = sky_color(path.d);
+                    c = make_float4(0.f + path.thr.x * sk.x, 0.f + path.thr.y * sk.y, 0.f + path.thr.z * sk.z, 0.f + 1.0f);
+                    ended = true;
+                }
+            } else { // Trace::CastRay(ray, depth, const Scene&), CPURayTrace/Trace.cpp:31-56, products taken front to back
+                const float rr = path.rr;
+                if (hit.ref == kNone) {
+                    f3 sk = sky_color(path.d);
+                    c = make_float4((path.thr.x * sk.x) * rr, (path.thr.y * sk.y) * rr, (path.thr.z * sk.z) * rr,
+                                    (path.thr.w * 1.0f) * rr);
+                    ended = true;
+                } else {
+                    f3 pos = path.o + hit.t * path.d;
+                    f3 N;
+                    uint32_t mat;
+                    if (hit.ref & kSphereBit) {
+                        const uint32_t si = hit.ref & ~kSphereBit;
+                        const float4 s0 = P.spheres[2 * si], s1 = P.spheres[2 * si + 1];
+                        N = normalize3(pos - mk3(s0.x, s0.y, s0.z));
+                        mat = __float_as_uint(s1.x);
+                        prim = __float_as_uint(s1.y);
+                    } else {
+                        if (STATS)
+                            cnt.trih++;
+                        const float4 q2 = P.tri_pos[3 * hit.ref + 2];
+                        N = tri_normal(P, hit.ref, hit.u, hit.v);
+                        prim = __float_as_uint(q2.y);
+                        mat = __float_as_uint(q2.z);
+                    }
+                    const float4 m0 = P.mats[2 * mat], m1 = P.mats[2 * mat + 1];
+                    const uint32_t mkind = __float_as_uint(m1.x);
+                    const float param = m1.y;
+                    path.thr = make_float4((path.thr.x * m0.x) * rr, (path.thr.y * m0.y) * rr, (path.thr.z * m0.z) * rr,
+                                           (path.thr.w * m0.w) * rr);
+                    if (mkind == RT_MAT_EMIT) { // LightEmit::getIrradiance, Materials/LightEmit.hpp:11-14
+                        c = path.thr;
+                        ended = true;
+                    } else {
+                        f3 no, nd;
+                        if (mkind == RT_MAT_DIELECTRIC) { // no reference counterpart: Snell + Schlick
+                            f3 unit = normalize3(path.d);
+                            bool front = dot3(unit, N) < 0.0f;
+                            f3 nn = front ? N : -N;
+                            float ri = front ? (1.0f / param) : param;
+                            float dn = dot3(-unit, nn);
+                            float cosT = (1.0f < dn) ? 1.0f : dn;
+                            float sinT = sqrtf(1.0f - cosT * cosT);
+                            bool cannot = ri * sinT > 1.0f;
+                            float pick = rng01(path.key, dim + 3u);
+                            f3 bias = nn * 1e-4f;
+                            if (cannot || reflectance(cosT, ri) > pick) {
+                                nd = unit - nn * dot3(unit, nn) * 2.f;
+                                no = pos + bias;
+                            } else {
+                                f3 perp = ri * (unit + cosT * nn);
+                                f3 par = nn * -sqrtf(fabsf(1.0f - dot3(perp, perp)));
+                                nd = perp + par;
+                                no = pos - bias;
+                            }
+                        } else { // Lambertian (Materials/Lambertian.hpp:16-29) or Metal (Materials/Metal.hpp:15-31)
+                            f3 bias = N * 1e-4f;
+                            float u1 = rng01(path.key, dim + 1u);
+                            float u2 = rng01(path.key, dim + 2u);
+                            f3 rnd = cosine_dir(N, u1, u2);
+                            if (mkind == RT_MAT_METAL) {
+                                f3 refl = path.d - N * dot3(path.d, N) * 2.f;
+                                nd = normalize3(rnd * param + refl * (1 - param));
+                            } else {
+                                nd = rnd;
+                            }
+                            no = pos + bias;
+                        }
+                        path.o = no;
+                        path.d = nd;
+                        // entry test of the next CastRay call (Trace.cpp:33-38): roulette, then the depth cap
+                        float nrr = 1.0f;
+                        if (path.depth > 1)
+                            nrr = rng01(path.key, 3u + 4u * (uint32_t)path.depth) < 0.8f ? 1.0f / 0.8f : 0.0f;
+                        if (path.depth > P.bounce_limit || nrr == 0.0f)
+                            ended = true; // that call returns zero
+                        path.rr = nrr;
+                    }
+                }
+            }
+            if (first && P.primary != nullptr && P.chunk_first + (int)(cidx / P.npix) == P.first_sample)
+                P.primary[cidx % P.npix] = prim;
+            if (ended)
+                P.colors[cidx] = c;
+        }
+        // ---- continuing paths go to the next level's queue, compacted per wave ----
+        const bool cont = live && !ended;
+        const unsigned long long cmask = __ballot(cont);
+        if (cmask != 0ull) {
+            unsigned int obase = 0;
+            if (lane == 0)
+                obase = atomicAdd(P.n_out, (unsigned int)__builtin_popcountll(cmask));
+            obase = __builtin_amdgcn_readfirstlane(obase);
+            if (cont) {
+                const size_t slot = (size_t)obase + (size_t)__builtin_popcountll(cmask & ((1ull << lane) - 1ull));
+                P.q_out[4 * slot] = make_float4(path.o.x, path.o.y, path.o.z, path.d.x);
+                P.q_out[4 * slot + 1] = make_float4(path.d.y, path.d.z, path.thr.x, path.thr.y);
+                P.q_out[4 * slot + 2] = make_float4(path.thr.z, path.thr.w, path.rr, __uint_as_float(path.key));
+                P.q_out[4 * slot + 3] = make_float4(__uint_as_float(cidx), __uint_as_float((uint32_t)path.depth), 0.f, 0.f);
+            }
+        }
+    }
+    unsigned long long r = wave_sum(cnt.rays);
+    if (lane == 0)
+        atomicAdd(&P.counters[0], r);
+    if (STATS) {
+        unsigned long long b = wave_sum(cnt.box), t = wave_sum(cnt.tri), s = wave_sum(cnt.sph), h = wave_sum(cnt.trih);
+        if (lane == 0) {
+            atomicAdd(&P.counters[1], b);
+            atomicAdd(&P.counters[2], t);
+            atomicAdd(&P.counters[3], s);
+            atomicAdd(&P.counters[4], h);
+        }
+    }
+}
+
+// Folds the S per-sample colours of every owned pixel into the running mean, in sample order:
+// pixel = (pixel*(n-1) + colour_n)/n, Renderer/TraceMethods.cpp:59.
+__global__ void __launch_bounds__(256) k_fold(float4 *image, const float4 *colors, uint32_t npix, int W, int tiles_x,
+                                              int tile_rank, int tile_world, int chunk_first, int S) {
+    const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
+    if (pixel >= npix)
+        return;
+    if (tile_world > 1) {
+        const uint32_t x = pixel % (uint32_t)W, y = pixel / (uint32_t)W;
+        const uint32_t tile = (y >> 3) * (uint32_t)tiles_x + (x >> 3);
+        if ((int)(tile % (uint32_t)tile_world) != tile_rank)
+            return;
+    }
+    float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (chunk_first > 1)
+        px = image[pixel];
+    for (int s = 0; s < S; s++) {
+        const int n = chunk_first + s;
+        const float4 c = colors[(size_t)s * npix + pixel];
+        const float nm1 = static_cast<float>((float)n - 1.f), nf = static_cast<float>(n);
+        px = make_float4((px.x * nm1 + c.x) / nf, (px.y * nm1 + c.y) / nf, (px.z * nm1 + c.z) / nf, (px.w * nm1 + c.w) / nf);
+    }
+    image[pixel] = px;
+}
+
 } // namespace
 
 // ===================================================================== host side of the C ABI
@@ -482,6 +905,7 @@ struct rt_ctx {
     float4 *d_nodes = nullptr, *d_tri_pos = nullptr, *d_tri_nrm = nullptr, *d_spheres = nullptr, *d_mats = nullptr;
     uint32_t n_nodes = 0;
     bool has_scene = false;
+    double expected_visits = 0.0; // sum of node box areas / root box area: nodes a random ray through the root meets
     rt_camera cam;
     bool has_camera = false;
     rt_options opt;
@@ -496,7 +920,11 @@ struct rt_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t pending = 0;
     int num_cus = 0;
-    int blocks_per_cu[4] = {0, 0, 0, 0};
+    int blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // [nested | wavefront][estimator][stats]
+    // wavefront workspace: per-sample colour buffer, two ping-pong path queues, per-level cursors/counters
+    float4 *d_colors = nullptr, *d_q[2] = {nullptr, nullptr};
+    unsigned int *d_levels = nullptr; // [2 * kMaxLevels]: cursor[l], count[l]
+    size_t colors_cap = 0, q_cap = 0; // capacities in float4 / records
 };
 
 namespace {
@@ -541,9 +969,10 @@ template <class T> int upload(rt_ctx *ctx, float4 **dst, const std::vector<T> &s
     return RT_OK;
 }
 
-template <bool OLD, bool STATS> int occupancy(int *out) {
+template <bool PL, bool OLD, bool STATS> int occupancy(int *out) {
     int n = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<OLD, STATS>, 256, 0);
+    hipError_t e = PL ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS>, 256, 0)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<OLD, STATS>, 256, 0);
     if (e != hipSuccess || n < 1)
         n = 1;
     if (n > 8)
@@ -605,28 +1034,97 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 64, ctx->stream));
     const bool old = o.estimator == RT_EST_OLD_RECURSIVE;
     const bool st = o.collect_stats != 0;
-    const int variant = (old ? 2 : 0) + (st ? 1 : 0);
-    uint32_t waves_needed = P.n_my_tiles;
-    uint32_t blocks = (uint32_t)ctx->num_cus * (uint32_t)ctx->blocks_per_cu[variant];
-    if (blocks > (waves_needed + 3) / 4)
-        blocks = (waves_needed + 3) / 4;
-    if (blocks < 1)
-        blocks = 1;
+    int trav = o.traversal;
+    if (trav == RT_TRAV_AUTO)
+        trav = ctx->expected_visits >= 512.0 ? RT_TRAV_WAVE : RT_TRAV_LANE;
+    P.wave_sync = trav == RT_TRAV_WAVE ? 1 : 0;
+    const int variant = (trav == RT_TRAV_NESTED ? 0 : 4) + (old ? 2 : 0) + (st ? 1 : 0);
+    const uint32_t full_grid = (uint32_t)ctx->num_cus * (uint32_t)ctx->blocks_per_cu[variant];
     if (ctx->pending == ctx->events.size()) {
         hipEvent_t a, b;
         RT_HIP_CHECK(ctx, hipEventCreate(&a));
         RT_HIP_CHECK(ctx, hipEventCreate(&b));
         ctx->events.emplace_back(a, b);
     }
-    RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
-    dim3 grid(blocks), block(256);
-    switch (variant) {
-    case 0: hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, ctx->stream, P); break;
-    case 1: hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, ctx->stream, P); break;
-    case 2: hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, ctx->stream, P); break;
-    default: hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, ctx->stream, P); break;
+    dim3 block(256);
+    if (trav == RT_TRAV_NESTED) {
+        uint32_t blocks = full_grid;
+        if (blocks > (P.n_my_tiles + 3) / 4)
+            blocks = (P.n_my_tiles + 3) / 4;
+        if (blocks < 1)
+            blocks = 1;
+        dim3 grid(blocks);
+        RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
+        switch (variant) {
+        case 0: hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, ctx->stream, P); break;
+        case 1: hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, ctx->stream, P); break;
+        case 2: hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, ctx->stream, P); break;
+        default: hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, ctx->stream, P); break;
+        }
+        RT_HIP_CHECK(ctx, hipGetLastError());
+        RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].second, ctx->stream));
+        ctx->pending++;
+        return RT_OK;
     }
-    RT_HIP_CHECK(ctx, hipGetLastError());
+    // ---- wavefront: samples in chunks of S; per chunk one k_path launch per bounce level, then k_fold ----
+    const size_t npix = (size_t)W * (size_t)H;
+    const size_t items_per_sample = (size_t)P.n_my_tiles * 64;
+    int S = count < kChunkSamples ? count : kChunkSamples;
+    if (items_per_sample > 0 && (size_t)S * items_per_sample > kMaxItems)
+        S = (int)(kMaxItems / items_per_sample);
+    if (S < 1)
+        S = 1;
+    const size_t need_colors = (size_t)S * npix, need_q = (size_t)S * items_per_sample;
+    if (need_colors > ctx->colors_cap || need_q > ctx->q_cap) {
+        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_colors) (void)hipFree(ctx->d_colors);
+        if (ctx->d_q[0]) (void)hipFree(ctx->d_q[0]);
+        if (ctx->d_q[1]) (void)hipFree(ctx->d_q[1]);
+        ctx->d_colors = ctx->d_q[0] = ctx->d_q[1] = nullptr;
+        ctx->colors_cap = ctx->q_cap = 0;
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_colors, need_colors * sizeof(float4)));
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_q[0], (need_q ? need_q : 1) * 4 * sizeof(float4)));
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_q[1], (need_q ? need_q : 1) * 4 * sizeof(float4)));
+        ctx->colors_cap = need_colors;
+        ctx->q_cap = need_q;
+    }
+    const int levels = old ? o.bounce_limit + 1 : (o.bounce_limit > 1 ? o.bounce_limit : 1);
+    P.colors = ctx->d_colors;
+    P.npix = (uint32_t)npix;
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
+    for (int done = 0; done < count || (count == 0 && done == 0); done += S) {
+        const int s_now = count - done < S ? count - done : S;
+        if (s_now <= 0)
+            break;
+        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_levels, 0, 2 * kMaxLevels * sizeof(unsigned int), ctx->stream));
+        P.S = s_now;
+        P.chunk_first = first + done;
+        P.n_items = (uint32_t)((size_t)s_now * items_per_sample);
+        for (int level = 0; level < levels; level++) {
+            P.level = level;
+            P.q_in = ctx->d_q[level & 1];
+            P.q_out = ctx->d_q[(level + 1) & 1];
+            P.cursor = ctx->d_levels + level;
+            P.n_in = ctx->d_levels + kMaxLevels + level;
+            P.n_out = ctx->d_levels + kMaxLevels + level + 1;
+            uint32_t blocks = full_grid;
+            if (level == 0 && blocks > (P.n_items / 64 + 3) / 4)
+                blocks = (P.n_items / 64 + 3) / 4;
+            if (blocks < 1)
+                blocks = 1;
+            dim3 grid(blocks);
+            switch (variant) {
+            case 4: hipLaunchKernelGGL((k_path<false, false>), grid, block, 0, ctx->stream, P); break;
+            case 5: hipLaunchKernelGGL((k_path<false, true>), grid, block, 0, ctx->stream, P); break;
+            case 6: hipLaunchKernelGGL((k_path<true, false>), grid, block, 0, ctx->stream, P); break;
+            default: hipLaunchKernelGGL((k_path<true, true>), grid, block, 0, ctx->stream, P); break;
+            }
+            RT_HIP_CHECK(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_fold, dim3((unsigned)((npix + 255) / 256)), block, 0, ctx->stream, d_img, ctx->d_colors,
+                           (uint32_t)npix, W, P.tiles_x, o.tile_rank, o.tile_world, P.chunk_first, s_now);
+        RT_HIP_CHECK(ctx, hipGetLastError());
+    }
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].second, ctx->stream));
     ctx->pending++;
     return RT_OK;
@@ -674,7 +1172,7 @@ int rt_create(rt_ctx **out, int device) {
     rt_ctx *ctx = new rt_ctx();
     ctx->device = device;
     std::memset(&ctx->cam, 0, sizeof(ctx->cam));
-    ctx->opt = rt_options{4, RT_EST_SD_LOOP, 1u, 0.001f, 0, 1, 0, 0u};
+    ctx->opt = rt_options{4, RT_EST_SD_LOOP, 1u, 0.001f, 0, 1, 0, 0u, RT_TRAV_AUTO};
     auto bail = [&](const char *what) {
         std::fprintf(stderr, "rt_create: %s failed\n", what);
         delete ctx;
@@ -685,13 +1183,18 @@ int rt_create(rt_ctx **out, int device) {
     ctx->own_stream = true;
     if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) return bail("hipMalloc");
     if (hipMalloc((void **)&ctx->d_counters, 64) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void **)&ctx->d_levels, 2 * kMaxLevels * sizeof(unsigned int)) != hipSuccess) return bail("hipMalloc");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail("hipGetDeviceProperties");
     ctx->num_cus = prop.multiProcessorCount;
-    occupancy<false, false>(&ctx->blocks_per_cu[0]);
-    occupancy<false, true>(&ctx->blocks_per_cu[1]);
-    occupancy<true, false>(&ctx->blocks_per_cu[2]);
-    occupancy<true, true>(&ctx->blocks_per_cu[3]);
+    occupancy<false, false, false>(&ctx->blocks_per_cu[0]);
+    occupancy<false, false, true>(&ctx->blocks_per_cu[1]);
+    occupancy<false, true, false>(&ctx->blocks_per_cu[2]);
+    occupancy<false, true, true>(&ctx->blocks_per_cu[3]);
+    occupancy<true, false, false>(&ctx->blocks_per_cu[4]);
+    occupancy<true, false, true>(&ctx->blocks_per_cu[5]);
+    occupancy<true, true, false>(&ctx->blocks_per_cu[6]);
+    occupancy<true, true, true>(&ctx->blocks_per_cu[7]);
     *out = ctx;
     return RT_OK;
 }
@@ -707,6 +1210,10 @@ void rt_destroy(rt_ctx *ctx) {
     if (ctx->d_primary) (void)hipFree(ctx->d_primary);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_levels) (void)hipFree(ctx->d_levels);
+    if (ctx->d_colors) (void)hipFree(ctx->d_colors);
+    if (ctx->d_q[0]) (void)hipFree(ctx->d_q[0]);
+    if (ctx->d_q[1]) (void)hipFree(ctx->d_q[1]);
     for (auto &e : ctx->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -835,6 +1342,25 @@ int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_
         free_scene(ctx);
         return rc;
     }
+    // Surface-area estimate of the nodes a ray through the root box visits.  Thousands (a tree whose boxes
+    // barely prune, like the reference's stretched boxes on the 18520-triangle dragon) favour the
+    // wave-synchronous walk; tens to hundreds favour the per-lane walk.
+    {
+        auto area = [](const rt_node &nd) {
+            double e[3];
+            for (int k = 0; k < 3; k++) {
+                e[k] = (double)nd.pmax[k] - (double)nd.pmin[k];
+                if (!(e[k] > 0.0))
+                    e[k] = 0.0;
+            }
+            return 2.0 * (e[0] * e[1] + e[1] * e[2] + e[0] * e[2]);
+        };
+        double sum = 0.0;
+        for (uint32_t p = 0; p < m; p++)
+            sum += area(nodes[order_of[p]]);
+        const double ra = area(nodes[root]);
+        ctx->expected_visits = ra > 0.0 ? sum / ra : (double)m;
+    }
     ctx->n_nodes = m;
     ctx->has_scene = true;
     return RT_OK;
@@ -853,8 +1379,9 @@ int rt_set_options(rt_ctx *ctx, const rt_options *opt) {
     if (!ctx || !opt)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    if (opt->bounce_limit < 0 || opt->tile_world < 1 || opt->tile_rank < 0 || opt->tile_rank >= opt->tile_world ||
-        (opt->estimator != RT_EST_SD_LOOP && opt->estimator != RT_EST_OLD_RECURSIVE))
+    if (opt->bounce_limit < 0 || opt->bounce_limit > kMaxLevels - 2 || opt->tile_world < 1 || opt->tile_rank < 0 || opt->tile_rank >= opt->tile_world ||
+        (opt->estimator != RT_EST_SD_LOOP && opt->estimator != RT_EST_OLD_RECURSIVE) || opt->traversal < 0 ||
+        opt->traversal > RT_TRAV_NESTED)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad options");
     ctx->opt = *opt;
     return RT_OK;

@@ -6,6 +6,7 @@ import numpy as np
 from . import _native as N
 
 EST_SD_LOOP, EST_OLD_RECURSIVE = 0, 1
+TRAV_AUTO, TRAV_LANE, TRAV_WAVE, TRAV_NESTED = 0, 1, 2, 3
 MISS = 0xFFFFFFFF
 
 _STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_HIP", -4: "RT_ERR_NO_SCENE",
@@ -92,9 +93,9 @@ class Tracer:
         self._check(N.hip().rt_set_camera(self._ctx, C.byref(c)))
 
     def set_options(self, bounce_limit=4, estimator=EST_SD_LOOP, seed=1, jitter=0.001, tile_rank=0, tile_world=1,
-                    collect_stats=False, sample_offset=0):
+                    collect_stats=False, sample_offset=0, traversal=0):
         o = N.OptionsC(bounce_limit, estimator, seed, jitter, tile_rank, tile_world, 1 if collect_stats else 0,
-                       sample_offset)
+                       sample_offset, traversal)
         self._check(N.hip().rt_set_options(self._ctx, C.byref(o)))
 
     def reset(self):

@@ -23,13 +23,15 @@ def tracer():
 def _compare(tracer, ps, os_, cam, w, h, spp, bounce, seed, jitter=0.001):
     tracer.upload(ps)
     tracer.set_camera(cam)
-    tracer.set_options(bounce_limit=bounce, estimator=R.EST_OLD_RECURSIVE, seed=seed, jitter=jitter, collect_stats=True)
-    img, prim, st = tracer.trace(w, h, 1, spp, want_primary=True)
     opt = O.make_options(bounce_limit=bounce, seed=seed, jitter=jitter, trig=O.TRIG_POLY, accum=O.ACCUM_FORWARD)
     oimg, oprim, ost = os_.render(oracle_camera(cam), opt, w, h, 1, spp, want_primary=True)
-    assert np.count_nonzero(prim != oprim) == 0
-    assert (st.rays, st.box_tests, st.tri_tests, st.sph_tests) == (ost.rays, ost.box_tests, ost.tri_tests, ost.sph_tests)
-    assert np.array_equal(bits(img), bits(oimg))
+    for trav in (R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED):   # every traversal variant: same bits
+        tracer.set_options(bounce_limit=bounce, estimator=R.EST_OLD_RECURSIVE, seed=seed, jitter=jitter,
+                           collect_stats=True, traversal=trav)
+        img, prim, st = tracer.trace(w, h, 1, spp, want_primary=True)
+        assert np.count_nonzero(prim != oprim) == 0, trav
+        assert (st.rays, st.box_tests, st.tri_tests, st.sph_tests) == (ost.rays, ost.box_tests, ost.tri_tests, ost.sph_tests), trav
+        assert np.array_equal(bits(img), bits(oimg)), trav
     return img, opt
 
 

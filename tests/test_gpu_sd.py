@@ -12,6 +12,10 @@ from helpers import O, R, WL, bits, oracle_camera, oracle_sd_scene, product_sd_s
 
 pytestmark = pytest.mark.gpu
 
+# every traversal variant must give the same bits: the wave-synchronous walk (scalar node fetches), the
+# per-lane walk, and the first-generation nested-loop kernel
+TRAVS = [R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED]
+
 
 @pytest.fixture(scope="module")
 def tracer():
@@ -25,11 +29,12 @@ def dragon2426(tracer):
     return product_sd_scene([WL.DRAGON_2426]), oracle_sd_scene([WL.DRAGON_2426])
 
 
-def test_primary_ids_dragon2426_400x225(tracer, dragon2426):
+@pytest.mark.parametrize("trav", TRAVS)
+def test_primary_ids_dragon2426_400x225(tracer, dragon2426, trav):
     ps, os_ = dragon2426
     tracer.upload(ps)
     tracer.set_camera(WL.DRAGON_2426_CAMERA)
-    tracer.set_options(bounce_limit=8, jitter=0.0, collect_stats=True)
+    tracer.set_options(bounce_limit=8, jitter=0.0, collect_stats=True, traversal=trav)
     img, prim, st = tracer.trace(400, 225, 1, 1, want_primary=True)
     opt = O.make_options(bounce_limit=8, jitter=0.0, trig=O.TRIG_POLY)
     oimg, oprim, ost = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, 400, 225, 1, 1, want_primary=True)
@@ -52,11 +57,12 @@ def test_primary_ids_dragon2426_1080p(tracer, dragon2426):
         assert np.count_nonzero(prim != oprim) == 0
 
 
-def test_shaded_image_bit_exact(tracer, dragon2426):
+@pytest.mark.parametrize("trav", TRAVS)
+def test_shaded_image_bit_exact(tracer, dragon2426, trav):
     ps, os_ = dragon2426
     tracer.upload(ps)
     tracer.set_camera(WL.DRAGON_2426_CAMERA)
-    tracer.set_options(bounce_limit=8, seed=7, jitter=0.001, collect_stats=True)
+    tracer.set_options(bounce_limit=8, seed=7, jitter=0.001, collect_stats=True, traversal=trav)
     img, _, st = tracer.trace(320, 180, 1, 8)
     opt = O.make_options(bounce_limit=8, seed=7, jitter=0.001, trig=O.TRIG_POLY)
     oimg, _, ost = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, 320, 180, 1, 8)
@@ -85,16 +91,17 @@ def test_progressive_equals_batched(tracer, dragon2426):
     assert np.array_equal(bits(whole), bits(b))
 
 
-def test_tile_split_union(tracer, dragon2426):
+@pytest.mark.parametrize("trav", TRAVS)
+def test_tile_split_union(tracer, dragon2426, trav):
     ps, _ = dragon2426
     tracer.upload(ps)
     tracer.set_camera(WL.DRAGON_2426_CAMERA)
-    tracer.set_options(bounce_limit=4, seed=5)
+    tracer.set_options(bounce_limit=4, seed=5, traversal=trav)
     whole, _, st = tracer.trace(250, 141, 1, 2)  # not a multiple of the 8x8 tile
     acc = np.zeros_like(whole)
     rays = 0
     for r in range(3):
-        tracer.set_options(bounce_limit=4, seed=5, tile_rank=r, tile_world=3)
+        tracer.set_options(bounce_limit=4, seed=5, tile_rank=r, tile_world=3, traversal=trav)
         part, _, s = tracer.trace(250, 141, 1, 2)
         assert np.all((acc == 0) | (part == 0))
         acc += part
@@ -103,11 +110,12 @@ def test_tile_split_union(tracer, dragon2426):
     assert np.array_equal(bits(whole), bits(acc))
 
 
-def test_dragon18520_small(tracer):
+@pytest.mark.parametrize("trav", TRAVS)
+def test_dragon18520_small(tracer, trav):
     ps, os_ = product_sd_scene([WL.DRAGON_18520]), oracle_sd_scene([WL.DRAGON_18520])
     tracer.upload(ps)
     tracer.set_camera(WL.DRAGON_18520_CAMERA)
-    tracer.set_options(bounce_limit=8, seed=1, collect_stats=True)
+    tracer.set_options(bounce_limit=8, seed=1, collect_stats=True, traversal=trav)
     img, prim, st = tracer.trace(240, 135, 1, 2, want_primary=True)
     opt = O.make_options(bounce_limit=8, seed=1, trig=O.TRIG_POLY)
     oimg, oprim, ost = os_.render(oracle_camera(WL.DRAGON_18520_CAMERA), opt, 240, 135, 1, 2, want_primary=True)
