@@ -83,6 +83,7 @@ struct KParams {
     uint32_t seed;
     uint32_t sample_offset;
     int wave_sync;
+    uint32_t wave_min_rays;
     // wavefront launches (k_path)
     const float4 *q_in;         // path records of this level (4 x float4 each)
     float4 *q_out;              // path records of the next level
@@ -637,11 +638,14 @@ struct Path {
 // full waves, and no lane ever waits for a neighbour's longer path.  The per-sample colours are folded
 // into the running mean afterwards, in sample order, by k_fold, which reproduces the reference's
 // "pixel = (pixel*(n-1) + new)/n" (Renderer/TraceMethods.cpp:59) bit for bit.
-template <bool OLD, bool STATS>
-__global__ void __launch_bounds__(256) k_path(const KParams P) {
+template <bool OLD, bool STATS, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_path(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull};
     const uint32_t n_in = P.level == 0 ? P.n_items : *P.n_in;
+    // A level with too few rays to fill the chip is bound by the latency of one walk, which is shortest
+    // when every lane walks alone; a level that saturates the chip is bound by throughput.
+    const bool use_wave = P.wave_sync != 0 && n_in >= P.wave_min_rays;
     for (;;) {
         unsigned int base = 0;
         if (lane == 0)
@@ -712,7 +716,7 @@ __global__ void __launch_bounds__(256) k_path(const KParams P) {
         Best hit;
         if (live)
             cnt.rays++;
-        if (P.wave_sync) {
+        if (use_wave) {
             closest_hit_wave<OLD, STATS>(P, live, path.o, path.d, path.inv, hit, cnt);
         } else {
             hit.ref = kNone;
@@ -920,7 +924,7 @@ struct rt_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t pending = 0;
     int num_cus = 0;
-    int blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // [nested | wavefront][estimator][stats]
+    int blocks_per_cu[12] = {0}; // [nested | wavefront per-lane | wavefront wave-sync][estimator][stats]
     // wavefront workspace: per-sample colour buffer, two ping-pong path queues, per-level cursors/counters
     float4 *d_colors = nullptr, *d_q[2] = {nullptr, nullptr};
     unsigned int *d_levels = nullptr; // [2 * kMaxLevels]: cursor[l], count[l]
@@ -969,10 +973,11 @@ template <class T> int upload(rt_ctx *ctx, float4 **dst, const std::vector<T> &s
     return RT_OK;
 }
 
-template <bool PL, bool OLD, bool STATS> int occupancy(int *out) {
+template <int KERNEL, bool OLD, bool STATS> int occupancy(int *out) {
     int n = 0;
-    hipError_t e = PL ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS>, 256, 0)
-                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<OLD, STATS>, 256, 0);
+    hipError_t e = KERNEL == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, 8>, 256, 0)
+                   : KERNEL == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, 1>, 256, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<OLD, STATS>, 256, 0);
     if (e != hipSuccess || n < 1)
         n = 1;
     if (n > 8)
@@ -1038,8 +1043,9 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     if (trav == RT_TRAV_AUTO)
         trav = ctx->expected_visits >= 512.0 ? RT_TRAV_WAVE : RT_TRAV_LANE;
     P.wave_sync = trav == RT_TRAV_WAVE ? 1 : 0;
+    P.wave_min_rays = o.traversal == RT_TRAV_WAVE ? 0u : 65536u;
     const int variant = (trav == RT_TRAV_NESTED ? 0 : 4) + (old ? 2 : 0) + (st ? 1 : 0);
-    const uint32_t full_grid = (uint32_t)ctx->num_cus * (uint32_t)ctx->blocks_per_cu[variant];
+    const uint32_t full_grid = (uint32_t)ctx->num_cus * (uint32_t)ctx->blocks_per_cu[variant + (P.wave_sync && variant >= 4 ? 4 : 0)];
     if (ctx->pending == ctx->events.size()) {
         hipEvent_t a, b;
         RT_HIP_CHECK(ctx, hipEventCreate(&a));
@@ -1114,10 +1120,16 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
                 blocks = 1;
             dim3 grid(blocks);
             switch (variant) {
-            case 4: hipLaunchKernelGGL((k_path<false, false>), grid, block, 0, ctx->stream, P); break;
-            case 5: hipLaunchKernelGGL((k_path<false, true>), grid, block, 0, ctx->stream, P); break;
-            case 6: hipLaunchKernelGGL((k_path<true, false>), grid, block, 0, ctx->stream, P); break;
-            default: hipLaunchKernelGGL((k_path<true, true>), grid, block, 0, ctx->stream, P); break;
+            // wave-synchronous walk: register allocation capped at 64 VGPRs (8 waves per SIMD hide the scalar
+            // fetch latency; the spills land in the shading code, which runs once per ray); per-lane walk: uncapped
+            case 4: if (P.wave_sync) hipLaunchKernelGGL((k_path<false, false, 8>), grid, block, 0, ctx->stream, P);
+                    else hipLaunchKernelGGL((k_path<false, false, 1>), grid, block, 0, ctx->stream, P); break;
+            case 5: if (P.wave_sync) hipLaunchKernelGGL((k_path<false, true, 8>), grid, block, 0, ctx->stream, P);
+                    else hipLaunchKernelGGL((k_path<false, true, 1>), grid, block, 0, ctx->stream, P); break;
+            case 6: if (P.wave_sync) hipLaunchKernelGGL((k_path<true, false, 8>), grid, block, 0, ctx->stream, P);
+                    else hipLaunchKernelGGL((k_path<true, false, 1>), grid, block, 0, ctx->stream, P); break;
+            default: if (P.wave_sync) hipLaunchKernelGGL((k_path<true, true, 8>), grid, block, 0, ctx->stream, P);
+                     else hipLaunchKernelGGL((k_path<true, true, 1>), grid, block, 0, ctx->stream, P); break;
             }
             RT_HIP_CHECK(ctx, hipGetLastError());
         }
@@ -1187,14 +1199,18 @@ int rt_create(rt_ctx **out, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail("hipGetDeviceProperties");
     ctx->num_cus = prop.multiProcessorCount;
-    occupancy<false, false, false>(&ctx->blocks_per_cu[0]);
-    occupancy<false, false, true>(&ctx->blocks_per_cu[1]);
-    occupancy<false, true, false>(&ctx->blocks_per_cu[2]);
-    occupancy<false, true, true>(&ctx->blocks_per_cu[3]);
-    occupancy<true, false, false>(&ctx->blocks_per_cu[4]);
-    occupancy<true, false, true>(&ctx->blocks_per_cu[5]);
-    occupancy<true, true, false>(&ctx->blocks_per_cu[6]);
-    occupancy<true, true, true>(&ctx->blocks_per_cu[7]);
+    occupancy<0, false, false>(&ctx->blocks_per_cu[0]);
+    occupancy<0, false, true>(&ctx->blocks_per_cu[1]);
+    occupancy<0, true, false>(&ctx->blocks_per_cu[2]);
+    occupancy<0, true, true>(&ctx->blocks_per_cu[3]);
+    occupancy<1, false, false>(&ctx->blocks_per_cu[4]);
+    occupancy<1, false, true>(&ctx->blocks_per_cu[5]);
+    occupancy<1, true, false>(&ctx->blocks_per_cu[6]);
+    occupancy<1, true, true>(&ctx->blocks_per_cu[7]);
+    occupancy<2, false, false>(&ctx->blocks_per_cu[8]);
+    occupancy<2, false, true>(&ctx->blocks_per_cu[9]);
+    occupancy<2, true, false>(&ctx->blocks_per_cu[10]);
+    occupancy<2, true, true>(&ctx->blocks_per_cu[11]);
     *out = ctx;
     return RT_OK;
 }
