@@ -9,7 +9,7 @@ out = {}
 for path in sorted(glob.glob(sys.argv[1] + "/*/*/*_counter_collection.csv")):
     with open(path) as fh:
         for row in csv.DictReader(fh):
-            if "k_trace" not in row["Kernel_Name"] and "k_path" not in row["Kernel_Name"]:
+            if not any(k in row["Kernel_Name"] for k in ("k_trace", "k_path", "k_fold")):
                 continue
             out.setdefault(row["Counter_Name"], 0.0)
             out[row["Counter_Name"]] += float(row["Counter_Value"])

@@ -18,6 +18,7 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--stats", action="store_true")
 ap.add_argument("--bounce", type=int, default=0)
 ap.add_argument("--trav", type=int, default=0)
+ap.add_argument("--image", action="store_true", help="also copy the mean image to the host (PCIe-inclusive total_ms)")
 a = ap.parse_args()
 wl = WL.make_workload(a.workload)
 W, H, spp = a.width or wl.width, a.height or wl.height, a.spp or wl.spp
@@ -27,7 +28,7 @@ t.set_camera(wl.camera)
 t.set_options(bounce_limit=a.bounce or wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
               collect_stats=a.stats, traversal=a.trav)
 for i in range(a.reps):
-    _, _, st = t.trace(W, H, 1, spp, want_image=False)
+    _, _, st = t.trace(W, H, 1, spp, want_image=a.image)
     print(f"{a.workload} {W}x{H} spp={spp} rep={i}: rays={st.rays} kernel_ms={st.kernel_ms:.3f} "
-          f"Mrays/s={st.rays / st.kernel_ms / 1e3:.2f} box={st.box_tests} tri={st.tri_tests} sph={st.sph_tests}", flush=True)
+          f"Mrays/s={st.rays / st.kernel_ms / 1e3:.2f} total_ms={st.total_ms:.3f} box={st.box_tests} tri={st.tri_tests} sph={st.sph_tests}", flush=True)
 t.close()
