@@ -80,7 +80,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the tracer has no CPU path")
-    rank, world, local_rank = P.init_from_env("nccl")
+    # RT_BENCH_BACKEND=gloo lets the N > 1 path be rehearsed with several ranks sharing one GPU (RCCL refuses that)
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend != "nccl":
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(n_dev, 1))
+    rank, world, local_rank = P.init_from_env(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -497,28 +497,50 @@ __global__ void __launch_bounds__(256) k_trace(const KParams P) {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const v4f __attribute__((address_space(4))) *cf4ptr; // constant address space: scalar loads
 
-template <bool OLD, bool STATS>
-RT_D void closest_hit_wave(const KParams &P, const bool live, const f3 o, const f3 d, const f3 inv, Best &best,
-                           Cnt &cnt) {
+// OCT >= 0: every live lane's direction has the same sign pattern (the usual case for the camera rays of
+// a tile).  The near/far plane of each axis is then fixed at compile time instead of chosen by six
+// per-lane selects on the products; "(pNear - o) * inv" is the very product the reference keeps after
+// its swap, so the values are unchanged.
+template <bool OLD, bool STATS, int OCT> // OCT = sign bits (x | y<<1 | z<<2) shared by the wave, or -1 = mixed
+RT_D void wave_walk(const KParams &P, const bool live, const f3 o, const f3 d, const f3 inv, Best &best, Cnt &cnt,
+                    const bool nx, const bool ny, const bool nz) {
+    constexpr bool UNI = OCT >= 0;
+    constexpr bool ux = UNI && (OCT & 1), uy = UNI && (OCT & 2), uz = UNI && (OCT & 4);
     typedef const char __attribute__((address_space(4))) *cbytes;
     const cbytes nodes = (cbytes)(uintptr_t)P.nodes;
     const cf4ptr tri_pos = (cf4ptr)(uintptr_t)P.tri_pos;
     const cf4ptr spheres = (cf4ptr)(uintptr_t)P.spheres;
-    best.t = __builtin_inff();
-    best.u = 0.0f;
-    best.v = 0.0f;
-    best.ref = kNone;
     Best outer = best;
     uint32_t inner_end = kNone;
     uint32_t resume = live ? 0u : kNone;
-    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     const uint32_t n = P.n_nodes;
     uint32_t cur = 0;
     while (cur < n) {
         const v4f a = *(cf4ptr)(nodes + cur * 32u), b = *(cf4ptr)(nodes + cur * 32u + 16u);
         const uint32_t skip = __float_as_uint(b.z);
         const uint32_t kind = __float_as_uint(b.w);
-        const float dx0 = a.x - o.x, dx1 = a.w - o.x, dy0 = a.y - o.y, dy1 = b.x - o.y, dz0 = a.z - o.z, dz1 = b.y - o.z;
+        float nearx, farx, neary, fary, nearz, farz;
+        if (UNI) {
+            const float pnx = ux ? a.w : a.x, pfx = ux ? a.x : a.w;
+            const float pny = uy ? b.x : a.y, pfy = uy ? a.y : b.x;
+            const float pnz = uz ? b.y : a.z, pfz = uz ? a.z : b.y;
+            nearx = (pnx - o.x) * inv.x;
+            farx = (pfx - o.x) * inv.x;
+            neary = (pny - o.y) * inv.y;
+            fary = (pfy - o.y) * inv.y;
+            nearz = (pnz - o.z) * inv.z;
+            farz = (pfz - o.z) * inv.z;
+        } else {
+            const float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
+            const float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
+            const float t0z = (a.z - o.z) * inv.z, t1z = (b.y - o.z) * inv.z;
+            nearx = nx ? t1x : t0x;
+            farx = nx ? t0x : t1x;
+            neary = ny ? t1y : t0y;
+            fary = ny ? t0y : t1y;
+            nearz = nz ? t1z : t0z;
+            farz = nz ? t0z : t1z;
+        }
         const bool act = resume <= cur;
         if (OLD) {
             if (act && cur == inner_end) {
@@ -529,18 +551,16 @@ RT_D void closest_hit_wave(const KParams &P, const bool live, const f3 o, const 
         }
         if (STATS)
             cnt.box += act ? 1ull : 0ull;
-        float t0x = dx0 * inv.x, t1x = dx1 * inv.x;
-        float t0y = dy0 * inv.y, t1y = dy1 * inv.y;
-        float t0z = dz0 * inv.z, t1z = dz1 * inv.z;
-        float nearx = nx ? t1x : t0x, farx = nx ? t0x : t1x;
-        float neary = ny ? t1y : t0y, fary = ny ? t0y : t1y;
-        float nearz = nz ? t1z : t0z, farz = nz ? t0z : t1z;
-        float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
-        float tmax = fminf(farz, fminf(fary, fminf(farx, best.t)));
-        const bool pass = act && !(tmax <= tmin);
-        if (act && !pass)
-            resume = skip;
-        const bool any = __builtin_amdgcn_ballot_w64(pass) != 0ull;
+        // reject iff min(far.., closest) <= max(near.., 1e-6); a NaN plane product drops out of min/max
+        // exactly as it drops out of the reference's "t0 > tMin ? t0 : tMin" selects
+        const float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+        const float tfar = fminf(farz, fminf(fary, farx));
+        const float tm = fminf(tfar, best.t);
+        const bool ok = !(tm <= tmin);
+        const bool pass = act & ok;
+        // two ballots of plain comparisons and a scalar AND: cheaper than one ballot of the combined flag
+        const bool any = (__builtin_amdgcn_ballot_w64(resume <= cur) & __builtin_amdgcn_ballot_w64(!(tm <= tmin))) != 0ull;
+        resume = (act & !ok) ? skip : resume;
         const uint32_t k = kind & 7u;
         const uint32_t slot = kind >> 3;
         uint32_t next = cur + 1; // == skip for every leaf kind except a mesh leaf nobody entered
@@ -615,6 +635,32 @@ RT_D void closest_hit_wave(const KParams &P, const bool live, const f3 o, const 
             if (!(best.t < outer.t))
                 best = outer;
         }
+    }
+}
+
+template <bool OLD, bool STATS>
+RT_D void closest_hit_wave(const KParams &P, const bool live, const f3 o, const f3 d, const f3 inv, Best &best,
+                           Cnt &cnt) {
+    best.t = __builtin_inff();
+    best.u = 0.0f;
+    best.v = 0.0f;
+    best.ref = kNone;
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
+    const unsigned long long mx = __builtin_amdgcn_ballot_w64(live && nx), my = __builtin_amdgcn_ballot_w64(live && ny),
+                             mz = __builtin_amdgcn_ballot_w64(live && nz);
+    const bool uniform = (mx == 0ull || mx == lm) && (my == 0ull || my == lm) && (mz == 0ull || mz == lm);
+    const int oct = uniform ? ((mx != 0ull ? 1 : 0) | (my != 0ull ? 2 : 0) | (mz != 0ull ? 4 : 0)) : -1;
+    switch (oct) {
+    case 0: wave_walk<OLD, STATS, 0>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 1: wave_walk<OLD, STATS, 1>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 2: wave_walk<OLD, STATS, 2>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 3: wave_walk<OLD, STATS, 3>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 4: wave_walk<OLD, STATS, 4>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 5: wave_walk<OLD, STATS, 5>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 6: wave_walk<OLD, STATS, 6>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 7: wave_walk<OLD, STATS, 7>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    default: wave_walk<OLD, STATS, -1>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
     }
 }
 
