@@ -171,7 +171,7 @@ RT_D void closest_hit(const KParams &P, const f3 o, const f3 d, const f3 inv, Be
     Best outer = best;         // OLD: the scene-level closest while inside a mesh's inner BVH
     uint32_t inner_end = kNone; // OLD: first node index after the current mesh's inner BVH
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
-    const uint32_t n = P.n_nodes;
+    const uint32_t n = P.n_nodes * 32u; // node records are addressed by byte offset (32 bytes each)
     uint32_t idx = 0;
     while (idx < n) {
         if (OLD) {
@@ -181,8 +181,9 @@ RT_D void closest_hit(const KParams &P, const f3 o, const f3 d, const f3 inv, Be
                 inner_end = kNone;
             }
         }
-        const float4 a = P.nodes[2 * idx];
-        const float4 b = P.nodes[2 * idx + 1];
+        const float4 *rec = (const float4 *)((const char *)P.nodes + idx);
+        const float4 a = rec[0];
+        const float4 b = rec[1];
         const uint32_t skip = __float_as_uint(b.z);
         const uint32_t kind = __float_as_uint(b.w);
         if (STATS)
@@ -200,7 +201,7 @@ RT_D void closest_hit(const KParams &P, const f3 o, const f3 d, const f3 inv, Be
             idx = skip;
             continue;
         }
-        idx = idx + 1;
+        idx = idx + 32u;
         const uint32_t k = kind & 7u;
         if (k == KIND_INTERNAL)
             continue;
@@ -495,7 +496,9 @@ __global__ void __launch_bounds__(256) k_trace(const KParams P) {
 // own running closest distance -- but the node (and triangle / sphere) record is fetched ONCE per
 // wave through the scalar data path into SGPRs instead of 64 times through the vector memory path.
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v8f __attribute__((ext_vector_type(8)));
 typedef const v4f __attribute__((address_space(4))) *cf4ptr; // constant address space: scalar loads
+typedef const v8f __attribute__((address_space(4))) *cf8ptr;
 
 // OCT >= 0: every live lane's direction has the same sign pattern (the usual case for the camera rays of
 // a tile).  The near/far plane of each axis is then fixed at compile time instead of chosen by six
@@ -512,61 +515,74 @@ RT_D void wave_walk(const KParams &P, const bool live, const f3 o, const f3 d, c
     const cf4ptr spheres = (cf4ptr)(uintptr_t)P.spheres;
     Best outer = best;
     uint32_t inner_end = kNone;
-    uint32_t resume = live ? 0u : kNone;
-    const uint32_t n = P.n_nodes;
-    uint32_t cur = 0;
-    while (cur < n) {
-        const v4f a = *(cf4ptr)(nodes + cur * 32u), b = *(cf4ptr)(nodes + cur * 32u + 16u);
-        const uint32_t skip = __float_as_uint(b.z);
-        const uint32_t kind = __float_as_uint(b.w);
-        float nearx, farx, neary, fary, nearz, farz;
-        if (UNI) {
-            const float pnx = ux ? a.w : a.x, pfx = ux ? a.x : a.w;
-            const float pny = uy ? b.x : a.y, pfy = uy ? a.y : b.x;
-            const float pnz = uz ? b.y : a.z, pfz = uz ? a.z : b.y;
-            nearx = (pnx - o.x) * inv.x;
-            farx = (pfx - o.x) * inv.x;
-            neary = (pny - o.y) * inv.y;
-            fary = (pfy - o.y) * inv.y;
-            nearz = (pnz - o.z) * inv.z;
-            farz = (pfz - o.z) * inv.z;
-        } else {
-            const float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
-            const float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
-            const float t0z = (a.z - o.z) * inv.z, t1z = (b.y - o.z) * inv.z;
-            nearx = nx ? t1x : t0x;
-            farx = nx ? t0x : t1x;
-            neary = ny ? t1y : t0y;
-            fary = ny ? t0y : t1y;
-            nearz = nz ? t1z : t0z;
-            farz = nz ? t0z : t1z;
-        }
-        const bool act = resume <= cur;
-        if (OLD) {
-            if (act && cur == inner_end) {
-                if (!(best.t < outer.t))
-                    best = outer;
-                inner_end = kNone;
+    uint32_t resume = live ? 0u : kNone; // byte offset of the next record this lane takes part in
+    uint32_t cur = 0;                     // byte offset of the wave's current record
+    // The scalar pipe issues one instruction per SIMD every four cycles, so the loop is written to need as
+    // few scalar instructions per node as possible: one 32-byte scalar load, byte offsets instead of indices,
+    // kind word 0 for internal nodes, and no bound check (the array ends with a terminator record).
+    for (;;) {
+        uint32_t skip, kind;
+        float tm, tmin; // kept as floats across the loop exit; flags are re-derived (a carried flag costs selects)
+        // inner loop: internal nodes only (kind word 0) -- the hot part of the walk
+        for (;;) {
+            const v8f r = *(cf8ptr)(nodes + cur);
+            const v4f a = {r[0], r[1], r[2], r[3]}, b = {r[4], r[5], r[6], r[7]};
+            skip = __float_as_uint(b.z);
+            kind = __float_as_uint(b.w);
+            float nearx, farx, neary, fary, nearz, farz;
+            if (UNI) {
+                const float pnx = ux ? a.w : a.x, pfx = ux ? a.x : a.w;
+                const float pny = uy ? b.x : a.y, pfy = uy ? a.y : b.x;
+                const float pnz = uz ? b.y : a.z, pfz = uz ? a.z : b.y;
+                nearx = (pnx - o.x) * inv.x;
+                farx = (pfx - o.x) * inv.x;
+                neary = (pny - o.y) * inv.y;
+                fary = (pfy - o.y) * inv.y;
+                nearz = (pnz - o.z) * inv.z;
+                farz = (pfz - o.z) * inv.z;
+            } else {
+                const float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
+                const float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
+                const float t0z = (a.z - o.z) * inv.z, t1z = (b.y - o.z) * inv.z;
+                nearx = nx ? t1x : t0x;
+                farx = nx ? t0x : t1x;
+                neary = ny ? t1y : t0y;
+                fary = ny ? t0y : t1y;
+                nearz = nz ? t1z : t0z;
+                farz = nz ? t0z : t1z;
             }
+            const bool act = resume <= cur;
+            if (OLD) {
+                if (act && cur == inner_end) {
+                    if (!(best.t < outer.t))
+                        best = outer;
+                    inner_end = kNone;
+                }
+            }
+            if (STATS)
+                cnt.box += (act && kind != kNone) ? 1ull : 0ull; // the terminator record is not a node
+            // reject iff min(far.., closest) <= max(near.., 1e-6); a NaN plane product drops out of min/max
+            // exactly as it drops out of the reference's "t0 > tMin ? t0 : tMin" selects
+            tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+            tm = fminf(fminf(farz, fminf(fary, farx)), best.t);
+            if (kind != 0u)
+                break;
+            // two ballots of plain comparisons and a scalar AND: cheaper than one ballot of the combined flag
+            const bool anyi = (__builtin_amdgcn_ballot_w64(resume <= cur) & __builtin_amdgcn_ballot_w64(!(tm <= tmin))) != 0ull;
+            resume = ((resume <= cur) & (tm <= tmin)) ? skip : resume;
+            cur = __builtin_amdgcn_readfirstlane(anyi ? cur + 32u : skip);
         }
-        if (STATS)
-            cnt.box += act ? 1ull : 0ull;
-        // reject iff min(far.., closest) <= max(near.., 1e-6); a NaN plane product drops out of min/max
-        // exactly as it drops out of the reference's "t0 > tMin ? t0 : tMin" selects
-        const float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
-        const float tfar = fminf(farz, fminf(fary, farx));
-        const float tm = fminf(tfar, best.t);
+        if (kind == kNone) // terminator record after the last node
+            break;
+        const bool act = resume <= cur;
         const bool ok = !(tm <= tmin);
         const bool pass = act & ok;
-        // two ballots of plain comparisons and a scalar AND: cheaper than one ballot of the combined flag
         const bool any = (__builtin_amdgcn_ballot_w64(resume <= cur) & __builtin_amdgcn_ballot_w64(!(tm <= tmin))) != 0ull;
         resume = (act & !ok) ? skip : resume;
         const uint32_t k = kind & 7u;
         const uint32_t slot = kind >> 3;
-        uint32_t next = cur + 1; // == skip for every leaf kind except a mesh leaf nobody entered
-        if (k == KIND_INTERNAL) {
-            next = any ? cur + 1 : skip;
-        } else if (!any) {
+        uint32_t next = cur + 32u; // == skip for every leaf kind except a mesh leaf nobody entered
+        if (!any) {
             if (OLD && k == KIND_MESH)
                 next = skip;
         } else if (k == KIND_TRI) {
@@ -1298,8 +1314,8 @@ int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null primitive array");
     if (order != RT_ORDER_RIGHT_FIRST && order != RT_ORDER_LEFT_FIRST)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad traversal order");
-    if (n_tris >= (1u << 29) || n_spheres >= (1u << 29))
-        return fail(ctx, RT_ERR_BAD_SCENE, "too many primitives");
+    if (n_tris >= (1u << 28) || n_spheres >= (1u << 28) || n_nodes >= (1u << 27))
+        return fail(ctx, RT_ERR_BAD_SCENE, "too many nodes or primitives");
 
     // 1. Walk the tree once in the reference's visiting order and record that order.
     std::vector<uint32_t> order_of; // emission position -> node index
@@ -1353,7 +1369,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_
             size[p] = 1 + size[pos_of[nd.left]];
     }
     // 3. Emit node records and the triangle arrays in leaf-visit order.
-    std::vector<float4> dn(2 * (size_t)m);
+    std::vector<float4> dn(2 * (size_t)m + 2); // + the terminator record
     std::vector<float4> tp, tn, sp(2 * (size_t)n_spheres), mt(2 * (size_t)n_mats);
     tp.reserve(3 * (size_t)n_tris);
     tn.reserve(3 * (size_t)n_tris);
@@ -1380,8 +1396,11 @@ int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_
             ref = nd.left;
         }
         dn[2 * (size_t)p] = make_float4(nd.pmin[0], nd.pmin[1], nd.pmin[2], nd.pmax[0]);
-        dn[2 * (size_t)p + 1] = make_float4(nd.pmax[1], nd.pmax[2], u2f(p + size[p]), u2f((ref << 3) | kind));
+        dn[2 * (size_t)p + 1] = make_float4(nd.pmax[1], nd.pmax[2], u2f((p + size[p]) * 32u), u2f((ref << 3) | kind));
     }
+    // terminator: a box no ray enters (NaN planes drop out of the slab test, closest <= FLT_MAX fails it), kind = all ones
+    dn[2 * (size_t)m] = make_float4(1.f, 1.f, 1.f, -1.f);
+    dn[2 * (size_t)m + 1] = make_float4(-1.f, -1.f, u2f(m * 32u), u2f(kNone));
     for (uint32_t i = 0; i < n_mats; i++) {
         mt[2 * (size_t)i] = make_float4(mats[i].albedo[0], mats[i].albedo[1], mats[i].albedo[2], mats[i].albedo[3]);
         mt[2 * (size_t)i + 1] = make_float4(u2f(mats[i].kind), mats[i].param, 0.f, 0.f);
