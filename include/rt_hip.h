@@ -100,13 +100,23 @@ enum {
     RT_ORDER_LEFT_FIRST = 1   /* BVH::intersect / sd::BVH::Intersect recurse left first, BVH.hpp:143-144 */
 };
 
-/* How a wave walks the node array.  Every choice performs, per ray, exactly the reference's slab and
- * primitive tests in the reference's order; they differ only in how node records are fetched. */
+/* How the closest hit of a ray is found.  Every choice returns, per ray, exactly the hit the reference
+ * traversal returns (same primitive, same t, u, v bits).
+ *   LANE / WAVE / NESTED perform the reference's own slab and primitive tests in the reference's visiting
+ *   order over the reference's node boxes; they differ only in how node records are fetched.
+ *   FAST derives the same result from the reference's LEAF boxes alone, walking a surface-area-heuristic
+ *   hierarchy of exact unions the upload builds above them (see rt_upload_scene); it does far fewer tests
+ *   when the reference's interior boxes prune badly.  FAST_REPLAY forces every ray through FAST's ordered
+ *   replay procedure, which normally resolves only rays whose winning hit lies in front of its own leaf
+ *   box's entry distance (a verification aid). */
 enum {
-    RT_TRAV_AUTO = 0,
-    RT_TRAV_LANE = 1,  /* every lane follows its own index; node records through the vector memory path */
-    RT_TRAV_WAVE = 2,  /* the wave advances together; node records through the scalar data path */
-    RT_TRAV_NESTED = 3 /* first-generation kernel: one 8x8 tile per wave, nested sample/bounce loops, per-lane walk */
+    RT_TRAV_AUTO = 0,      /* = RT_TRAV_FAST */
+    RT_TRAV_LANE = 1,      /* reference order; every lane follows its own index; node records through the vector memory path */
+    RT_TRAV_WAVE = 2,      /* reference order; the wave advances together; node records through the scalar data path */
+    RT_TRAV_NESTED = 3,    /* reference order; first-generation kernel: one 8x8 tile per wave, nested sample/bounce loops */
+    RT_TRAV_FAST = 4,
+    RT_TRAV_FAST_REPLAY = 5,
+    RT_TRAV_REFERENCE = 6  /* reference order; LANE or WAVE chosen from a surface-area estimate of the visits per ray */
 };
 
 typedef struct rt_options {
@@ -128,6 +138,7 @@ typedef struct rt_stats {
     uint64_t tri_tests;
     uint64_t sph_tests;
     uint64_t tri_hits;  /* traversals that ended on a triangle */
+    uint64_t replays;   /* RT_TRAV_FAST: rays resolved by the ordered replay (always counted) */
     float kernel_ms;     /* HIP-event time of the last trace kernel on the context's stream */
     float total_ms;      /* host wall time of the call (rt_trace only) */
     float kernel_ms_sum; /* HIP-event time summed over the launches since the previous sync */
@@ -143,7 +154,9 @@ const char *rt_last_error(rt_ctx *ctx);
 /* Takes the scene snapshot the reference's load methods take (LoadSdSceneCPU::load,
  * Renderer/LoadMethods.cpp:55-61; LoadSceneCPU::load, :65-73) and lays it out in HBM.  `nodes`/`tris`
  * may point straight at sd::NodeStorage::nodes / sd::TriangleStorage::triangles.  `order` says which
- * child the reference traversal visits first (RT_ORDER_*). */
+ * child the reference traversal visits first (RT_ORDER_*).  Two node arrays are built: the reference's
+ * own tree re-laid in its visiting order (RT_TRAV_LANE/WAVE/NESTED), and for RT_TRAV_FAST a second
+ * hierarchy over the same leaf boxes (kept bit for bit) whose interior boxes are exact unions. */
 int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt_tri *tris,
                     uint32_t n_tris, const rt_sphere *spheres, uint32_t n_spheres, const rt_material *mats,
                     uint32_t n_mats, int order);

@@ -44,7 +44,7 @@ class OptionsC(C.Structure):  # rt_options
 
 class StatsC(C.Structure):  # rt_stats
     _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("sph_tests", C.c_uint64),
-                ("tri_hits", C.c_uint64), ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("kernel_ms_sum", C.c_float),
+                ("tri_hits", C.c_uint64), ("replays", C.c_uint64), ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("kernel_ms_sum", C.c_float),
                 ("launches", C.c_uint32)]
 
 

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "rt_hip.h"
+#include "fast_bvh.hpp"
 
 #define RT_HD __host__ __device__ __forceinline__
 #define RT_D __device__ __forceinline__
@@ -66,6 +67,7 @@ constexpr size_t kMaxItems = 48u << 20;    // work items (pixel samples) per chu
 // ------------------------------------------------------------------ kernel parameters
 struct KParams {
     const float4 *nodes; // 2 x float4 per node, reference visiting order
+    const float4 *fnodes; // 2 x float4 per node of the fast tree (pre-order, exact-union boxes over the reference's leaf boxes)
     const float4 *tri_pos; // 3 x float4 per triangle slot: p0, e1, e2, prim id, material
     const float4 *tri_nrm; // 3 x float4 per triangle slot: n0, n1, n2
     const float4 *spheres; // 2 x float4 per sphere
@@ -73,8 +75,10 @@ struct KParams {
     float4 *image;
     uint32_t *primary;
     unsigned int *queue;
-    unsigned long long *counters; // rays, box, tri, sph, tri_hits
+    unsigned long long *counters; // rays, box, tri, sph, tri_hits, replays
     uint32_t n_nodes;
+    uint32_t n_fnodes;
+    int force_replay; // fast walk: resolve every ray by the ordered replay (verification aid)
     uint32_t n_my_tiles;
     int W, H, tiles_x;
     int tile_rank, tile_world;
@@ -154,7 +158,7 @@ struct Best {
     uint32_t ref; // triangle slot, kSphereBit | sphere index, or kNone
 };
 struct Cnt {
-    unsigned long long rays, box, tri, sph, trih;
+    unsigned long long rays, box, tri, sph, trih, replay;
 };
 
 // Closest hit in the reference's own visiting order.  One iteration = one node of the reference
@@ -430,7 +434,7 @@ RT_D unsigned long long wave_sum(unsigned long long v) {
 template <bool OLD, bool STATS>
 __global__ void __launch_bounds__(256) k_trace(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
-    Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull};
+    Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     for (;;) {
         unsigned int j = 0;
         if (lane == 0)
@@ -680,6 +684,202 @@ RT_D void closest_hit_wave(const KParams &P, const bool live, const f3 o, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast closest hit: the reference's RESULT without the reference's walk.
+//
+// In the reference traversal (SimplifiedData.cpp:430-462, BVH.hpp:124-148) the interior boxes only prune;
+// every interior box contains the leaf boxes below it, and the slab test is monotone in the box, so a leaf
+// whose own box passes "(1e-6, closest)" has ancestors that passed with the (larger or equal) closest of
+// their moment.  What the reference returns is therefore a function of its LEAVES alone.  Call a leaf a
+// candidate when the ray meets its box at all (slab test with closest = +inf) and its primitive test
+// reports a hit at distance t; let m be the slab test's entry distance max(near planes, 1e-6).  The
+// reference meets the candidates in its fixed visiting order `pos` and accepts one iff closest > m and
+// t < closest.  If the candidate with the smallest (t, pos) has m <= t, it is accepted when its turn comes
+// (everything accepted before it has a larger t) and nothing after it can replace it: it IS the result,
+// whatever happened to the other candidates.  So the walk below visits the device's own tight hierarchy
+// in any order, with no closest-distance pruning at all (a pruned leaf could hide exactly such a
+// candidate), keeps the minimum of (t, pos), and is done unless the winner has m > t -- rounding in a
+// grazing hit, or a sphere that touches its box.  Those rays are resolved by replay_ordered, which plays
+// the reference's acceptance rule over the candidates in `pos` order and needs no more than the fast tree.
+struct Cand {
+    float t, u, v;
+    float m;       // entry distance of the candidate's own leaf box
+    uint32_t ref;  // triangle slot or kSphereBit | sphere index
+    uint32_t pos;  // position of the leaf in the reference's visiting order
+    uint32_t mesh; // OLD: position of the enclosing mesh leaf, kNone for a scene-level primitive
+    float mesh_m;  // OLD: entry distance of that mesh leaf's box
+};
+
+template <bool OLD, bool STATS, class F>
+RT_D void fast_walk(const KParams &P, const f3 o, const f3 d, const f3 inv, Cnt &cnt, F &&consider) {
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const uint32_t n = P.n_fnodes * 32u;
+    uint32_t idx = 0;
+    uint32_t mesh = kNone, inner_end = kNone;
+    float mesh_m = 0.0f;
+    while (idx < n) {
+        if (OLD) {
+            if (idx == inner_end) {
+                mesh = kNone;
+                mesh_m = 0.0f;
+                inner_end = kNone;
+            }
+        }
+        const float4 *rec = (const float4 *)((const char *)P.fnodes + idx);
+        const float4 a = rec[0];
+        const float4 b = rec[1];
+        const uint32_t skip = __float_as_uint(b.z);
+        const uint32_t kind = __float_as_uint(b.w);
+        if (STATS)
+            cnt.box++;
+        const float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
+        const float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
+        const float t0z = (a.z - o.z) * inv.z, t1z = (b.y - o.z) * inv.z;
+        const float nearx = nx ? t1x : t0x, farx = nx ? t0x : t1x;
+        const float neary = ny ? t1y : t0y, fary = ny ? t0y : t1y;
+        const float nearz = nz ? t1z : t0z, farz = nz ? t0z : t1z;
+        const float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+        const float tmax = fminf(farz, fminf(fary, fminf(farx, __builtin_inff()))); // the slab test with closest = +inf
+        if (tmax <= tmin) {
+            idx = skip;
+            continue;
+        }
+        idx = idx + 32u;
+        const uint32_t k = kind & 7u;
+        if (k == KIND_INTERNAL)
+            continue;
+        const uint32_t slot = kind >> 3;
+        if (k == KIND_TRI) {
+            if (STATS)
+                cnt.tri++;
+            const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
+            const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+            const float EPSILON = 1e-7f;
+            f3 h = cross3(d, e2);
+            float det = dot3(e1, h);
+            if (!(det > -EPSILON && det < EPSILON)) {
+                float f = 1.0f / det;
+                f3 s = o - p0;
+                float u = f * dot3(s, h);
+                if (!(u < 0.0f || u > 1.0f)) {
+                    f3 q = cross3(s, e1);
+                    float v = f * dot3(d, q);
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        float t = f * dot3(e2, q);
+                        if (t > EPSILON)
+                            consider(Cand{t, u, v, tmin, slot, __float_as_uint(q2.w), mesh, mesh_m});
+                    }
+                }
+            }
+        } else if (OLD && k == KIND_SPHERE) {
+            if (STATS)
+                cnt.sph++;
+            const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
+            f3 oc = mk3(s0.x, s0.y, s0.z) - o;
+            float qa = dot3(d, d);
+            float qb = -2.0f * dot3(d, oc);
+            float qc = dot3(oc, oc) - s0.w * s0.w;
+            float disc = qb * qb - 4 * qa * qc;
+            if (!(disc < 0)) {
+                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
+                bool ok = !(t < 0);
+                if (!ok && __float_as_uint(s1.z) != 0u) {
+                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
+                    ok = !(t < 0);
+                }
+                if (ok)
+                    consider(Cand{t, 0.0f, 0.0f, tmin, kSphereBit | slot, __float_as_uint(s1.w), kNone, 0.0f});
+            }
+        } else if (OLD && k == KIND_MESH) { // the mesh's inner hierarchy follows inline, up to `skip`
+            mesh = slot;
+            mesh_m = tmin;
+            inner_end = skip;
+        }
+    }
+}
+
+// Plays the reference's acceptance rule over the candidates in the reference's visiting order.  One pass over
+// the fast tree finds the next candidate the reference would ACCEPT in its current state (between two
+// acceptances the state does not change, so everything in between is skipped for good); the number of passes
+// is the number of acceptances plus one.  A mesh (BVH.hpp:135-137 with Mesh::intersect, Mesh.hpp:154-160)
+// runs its own closest hit from +inf once its scene-level leaf box passes, and hands the result to the scene
+// level when the walk leaves it.
+template <bool OLD, bool STATS>
+RT_D void replay_ordered(const KParams &P, const f3 o, const f3 d, const f3 inv, Best &best, Cnt &cnt) {
+    const float inf = __builtin_inff();
+    float c_out = inf, c_in = inf;
+    Best b_out = {inf, 0.0f, 0.0f, kNone}, b_in = b_out;
+    uint32_t cur_mesh = kNone;
+    uint32_t lo = 0;
+    for (;;) {
+        const float c_after = (OLD && cur_mesh != kNone && c_in < c_out) ? c_in : c_out; // scene-level closest once the current mesh is left
+        Cand f;
+        f.pos = kNone;
+        f.t = inf;
+        f.u = f.v = f.m = f.mesh_m = 0.0f;
+        f.ref = f.mesh = kNone;
+        fast_walk<OLD, STATS>(P, o, d, inv, cnt, [&](const Cand &c) {
+            if (c.pos < lo || c.pos >= f.pos)
+                return;
+            bool ok;
+            if (!OLD || c.mesh == kNone)
+                ok = c_after > c.m && c.t < c_after;
+            else if (c.mesh == cur_mesh)
+                ok = c_in > c.m && c.t < c_in;
+            else
+                ok = c_after > c.mesh_m && c.t < inf; // entering that mesh: its closest starts at +inf
+            if (ok)
+                f = c;
+        });
+        if (f.pos == kNone)
+            break;
+        if (OLD && f.mesh != cur_mesh) {
+            if (cur_mesh != kNone && c_in < c_out) {
+                c_out = c_in;
+                b_out = b_in;
+            }
+            cur_mesh = f.mesh;
+            c_in = inf;
+            b_in.ref = kNone;
+        }
+        if (!OLD || f.mesh == kNone) {
+            c_out = f.t;
+            b_out = Best{f.t, f.u, f.v, f.ref};
+        } else {
+            c_in = f.t;
+            b_in = Best{f.t, f.u, f.v, f.ref};
+        }
+        lo = f.pos + 1u;
+    }
+    if (OLD && cur_mesh != kNone && c_in < c_out)
+        b_out = b_in;
+    best = b_out;
+}
+
+template <bool OLD, bool STATS>
+RT_D void closest_hit_fast(const KParams &P, const f3 o, const f3 d, const f3 inv, Best &best, Cnt &cnt) {
+    best.t = __builtin_inff();
+    best.u = 0.0f;
+    best.v = 0.0f;
+    best.ref = kNone;
+    uint32_t bpos = kNone;
+    float bm = 0.0f;
+    fast_walk<OLD, STATS>(P, o, d, inv, cnt, [&](const Cand &c) {
+        // t = +inf passes the primitive test's "t > EPSILON" but never the reference's "t < closest.t"
+        if ((c.t < best.t || (c.t == best.t && c.pos < bpos)) && c.t < __builtin_inff()) {
+            best = Best{c.t, c.u, c.v, c.ref};
+            bpos = c.pos;
+            bm = fmaxf(c.m, c.mesh_m);
+        }
+    });
+    if (best.ref == kNone) // no candidate: the reference accepts nothing either
+        return;
+    if (bm > best.t || P.force_replay != 0) {
+        cnt.replay++;
+        replay_ordered<OLD, STATS>(P, o, d, inv, best, cnt);
+    }
+}
+
 // Path state carried from one bounce level to the next.
 struct Path {
     f3 o, d, inv; // current ray
@@ -700,14 +900,15 @@ struct Path {
 // full waves, and no lane ever waits for a neighbour's longer path.  The per-sample colours are folded
 // into the running mean afterwards, in sample order, by k_fold, which reproduces the reference's
 // "pixel = (pixel*(n-1) + new)/n" (Renderer/TraceMethods.cpp:59) bit for bit.
-template <bool OLD, bool STATS, int WAVES_PER_SIMD>
-__global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_path(const KParams P) {
+constexpr int WALK_LANE = 0, WALK_WAVE = 1, WALK_FAST = 2;
+template <bool OLD, bool STATS, int WALK>
+__global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
-    Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull};
+    Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     const uint32_t n_in = P.level == 0 ? P.n_items : *P.n_in;
     // A level with too few rays to fill the chip is bound by the latency of one walk, which is shortest
     // when every lane walks alone; a level that saturates the chip is bound by throughput.
-    const bool use_wave = P.wave_sync != 0 && n_in >= P.wave_min_rays;
+    const bool use_wave = WALK == WALK_WAVE && n_in >= P.wave_min_rays;
     for (;;) {
         unsigned int base = 0;
         if (lane == 0)
@@ -778,14 +979,18 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_path(const KParams P) {
         Best hit;
         if (live)
             cnt.rays++;
-        if (use_wave) {
+        if (WALK == WALK_WAVE && use_wave) {
             closest_hit_wave<OLD, STATS>(P, live, path.o, path.d, path.inv, hit, cnt);
         } else {
             hit.ref = kNone;
             hit.t = 0.f;
             hit.u = hit.v = 0.f;
-            if (live)
-                closest_hit<OLD, STATS>(P, path.o, path.d, path.inv, hit, cnt);
+            if (live) {
+                if (WALK == WALK_FAST)
+                    closest_hit_fast<OLD, STATS>(P, path.o, path.d, path.inv, hit, cnt);
+                else
+                    closest_hit<OLD, STATS>(P, path.o, path.d, path.inv, hit, cnt);
+            }
         }
         // ---- shade: the path ends with a colour or continues with a new ray ----
         bool ended = false;
@@ -931,6 +1136,11 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_path(const KParams P) {
             atomicAdd(&P.counters[4], h);
         }
     }
+    if (WALK == WALK_FAST) {
+        unsigned long long rp = wave_sum(cnt.replay);
+        if (lane == 0 && rp != 0ull)
+            atomicAdd(&P.counters[5], rp);
+    }
 }
 
 // Folds the S per-sample colours of every owned pixel into the running mean, in sample order:
@@ -968,6 +1178,8 @@ struct rt_ctx {
     std::mutex mu;
     std::string err;
     // scene in HBM
+    float4 *d_fnodes = nullptr;
+    uint32_t n_fnodes = 0;
     float4 *d_nodes = nullptr, *d_tri_pos = nullptr, *d_tri_nrm = nullptr, *d_spheres = nullptr, *d_mats = nullptr;
     uint32_t n_nodes = 0;
     bool has_scene = false;
@@ -986,7 +1198,7 @@ struct rt_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t pending = 0;
     int num_cus = 0;
-    int blocks_per_cu[12] = {0}; // [nested | wavefront per-lane | wavefront wave-sync][estimator][stats]
+    int blocks_per_cu[16] = {0}; // [nested | wavefront per-lane | wavefront wave-sync | wavefront fast][estimator][stats]
     // wavefront workspace: per-sample colour buffer, two ping-pong path queues, per-level cursors/counters
     float4 *d_colors = nullptr, *d_q[2] = {nullptr, nullptr};
     unsigned int *d_levels = nullptr; // [2 * kMaxLevels]: cursor[l], count[l]
@@ -1010,6 +1222,9 @@ int fail(rt_ctx *ctx, int code, const std::string &msg) {
 
 void free_scene(rt_ctx *c) {
     if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_fnodes) (void)hipFree(c->d_fnodes);
+    c->d_fnodes = nullptr;
+    c->n_fnodes = 0;
     if (c->d_tri_pos) (void)hipFree(c->d_tri_pos);
     if (c->d_tri_nrm) (void)hipFree(c->d_tri_nrm);
     if (c->d_spheres) (void)hipFree(c->d_spheres);
@@ -1037,8 +1252,9 @@ template <class T> int upload(rt_ctx *ctx, float4 **dst, const std::vector<T> &s
 
 template <int KERNEL, bool OLD, bool STATS> int occupancy(int *out) {
     int n = 0;
-    hipError_t e = KERNEL == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, 8>, 256, 0)
-                   : KERNEL == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, 1>, 256, 0)
+    hipError_t e = KERNEL == 3   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, WALK_FAST>, 256, 0)
+                   : KERNEL == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, WALK_WAVE>, 256, 0)
+                   : KERNEL == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, WALK_LANE>, 256, 0)
                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<OLD, STATS>, 256, 0);
     if (e != hipSuccess || n < 1)
         n = 1;
@@ -1060,6 +1276,8 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     const rt_options &o = ctx->opt;
     KParams P;
     P.nodes = ctx->d_nodes;
+    P.fnodes = ctx->d_fnodes;
+    P.n_fnodes = ctx->n_fnodes;
     P.tri_pos = ctx->d_tri_pos;
     P.tri_nrm = ctx->d_tri_nrm;
     P.spheres = ctx->d_spheres;
@@ -1103,11 +1321,15 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     const bool st = o.collect_stats != 0;
     int trav = o.traversal;
     if (trav == RT_TRAV_AUTO)
+        trav = RT_TRAV_FAST;
+    if (trav == RT_TRAV_REFERENCE)
         trav = ctx->expected_visits >= 512.0 ? RT_TRAV_WAVE : RT_TRAV_LANE;
-    P.wave_sync = trav == RT_TRAV_WAVE ? 1 : 0;
+    P.force_replay = trav == RT_TRAV_FAST_REPLAY ? 1 : 0;
+    const int walk = trav == RT_TRAV_WAVE ? WALK_WAVE : (trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY) ? WALK_FAST : WALK_LANE;
+    P.wave_sync = walk == WALK_WAVE ? 1 : 0;
     P.wave_min_rays = o.traversal == RT_TRAV_WAVE ? 0u : 65536u;
     const int variant = (trav == RT_TRAV_NESTED ? 0 : 4) + (old ? 2 : 0) + (st ? 1 : 0);
-    const uint32_t full_grid = (uint32_t)ctx->num_cus * (uint32_t)ctx->blocks_per_cu[variant + (P.wave_sync && variant >= 4 ? 4 : 0)];
+    const uint32_t full_grid = (uint32_t)ctx->num_cus * (uint32_t)ctx->blocks_per_cu[variant + (variant >= 4 ? 4 * walk : 0)];
     if (ctx->pending == ctx->events.size()) {
         hipEvent_t a, b;
         RT_HIP_CHECK(ctx, hipEventCreate(&a));
@@ -1181,18 +1403,21 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
             if (blocks < 1)
                 blocks = 1;
             dim3 grid(blocks);
-            switch (variant) {
             // wave-synchronous walk: register allocation capped at 64 VGPRs (8 waves per SIMD hide the scalar
-            // fetch latency; the spills land in the shading code, which runs once per ray); per-lane walk: uncapped
-            case 4: if (P.wave_sync) hipLaunchKernelGGL((k_path<false, false, 8>), grid, block, 0, ctx->stream, P);
-                    else hipLaunchKernelGGL((k_path<false, false, 1>), grid, block, 0, ctx->stream, P); break;
-            case 5: if (P.wave_sync) hipLaunchKernelGGL((k_path<false, true, 8>), grid, block, 0, ctx->stream, P);
-                    else hipLaunchKernelGGL((k_path<false, true, 1>), grid, block, 0, ctx->stream, P); break;
-            case 6: if (P.wave_sync) hipLaunchKernelGGL((k_path<true, false, 8>), grid, block, 0, ctx->stream, P);
-                    else hipLaunchKernelGGL((k_path<true, false, 1>), grid, block, 0, ctx->stream, P); break;
-            default: if (P.wave_sync) hipLaunchKernelGGL((k_path<true, true, 8>), grid, block, 0, ctx->stream, P);
-                     else hipLaunchKernelGGL((k_path<true, true, 1>), grid, block, 0, ctx->stream, P); break;
+            // fetch latency; the spills land in the shading code, which runs once per ray); the others: uncapped
+#define RT_LAUNCH_PATH(OLD_, STATS_)                                                                                  \
+    do {                                                                                                              \
+        if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, 0, ctx->stream, P);   \
+        else if (walk == WALK_FAST) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_FAST>), grid, block, 0, ctx->stream, P); \
+        else hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_LANE>), grid, block, 0, ctx->stream, P);                     \
+    } while (0)
+            switch (variant) {
+            case 4: RT_LAUNCH_PATH(false, false); break;
+            case 5: RT_LAUNCH_PATH(false, true); break;
+            case 6: RT_LAUNCH_PATH(true, false); break;
+            default: RT_LAUNCH_PATH(true, true); break;
             }
+#undef RT_LAUNCH_PATH
             RT_HIP_CHECK(ctx, hipGetLastError());
         }
         hipLaunchKernelGGL(k_fold, dim3((unsigned)((npix + 255) / 256)), block, 0, ctx->stream, d_img, ctx->d_colors,
@@ -1209,13 +1434,14 @@ int sync_and_stats(rt_ctx *ctx, rt_stats *stats) {
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         if (ctx->pending > 0) {
-            unsigned long long h[5];
+            unsigned long long h[6];
             RT_HIP_CHECK(ctx, hipMemcpy(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost));
             stats->rays = h[0];
             stats->box_tests = h[1];
             stats->tri_tests = h[2];
             stats->sph_tests = h[3];
             stats->tri_hits = h[4];
+            stats->replays = h[5];
             float ms = 0.f, sum = 0.f;
             for (size_t i = 0; i < ctx->pending; i++) {
                 RT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
@@ -1273,6 +1499,10 @@ int rt_create(rt_ctx **out, int device) {
     occupancy<2, false, true>(&ctx->blocks_per_cu[9]);
     occupancy<2, true, false>(&ctx->blocks_per_cu[10]);
     occupancy<2, true, true>(&ctx->blocks_per_cu[11]);
+    occupancy<3, false, false>(&ctx->blocks_per_cu[12]);
+    occupancy<3, false, true>(&ctx->blocks_per_cu[13]);
+    occupancy<3, true, false>(&ctx->blocks_per_cu[14]);
+    occupancy<3, true, true>(&ctx->blocks_per_cu[15]);
     *out = ctx;
     return RT_OK;
 }
@@ -1368,56 +1598,145 @@ int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_
         else if (nd.flags == RT_NODE_MESH)
             size[p] = 1 + size[pos_of[nd.left]];
     }
-    // 3. Emit node records and the triangle arrays in leaf-visit order.
-    std::vector<float4> dn(2 * (size_t)m + 2); // + the terminator record
-    std::vector<float4> tp, tn, sp(2 * (size_t)n_spheres), mt(2 * (size_t)n_mats);
+    // 3. The fast tree: a surface-area-heuristic hierarchy over the reference's leaf boxes (see fast_bvh.hpp).
+    //    Scene-level leaves (triangles of the flat scene, spheres, mesh objects) form the top tree; the
+    //    triangles of a mesh object form that mesh's own tree, emitted inline right after the mesh's leaf
+    //    record, exactly as the reference nests Mesh::intersect inside the scene traversal.
+    struct MeshTree {
+        std::vector<fastbvh::Item> items;
+        std::vector<fastbvh::Node> nodes;
+    };
+    std::vector<fastbvh::Item> top_items;
+    std::vector<MeshTree> mesh_trees;
+    std::vector<uint32_t> mesh_of(m, kNone); // reference position of a mesh leaf -> index into mesh_trees
+    {
+        uint32_t mesh_end = 0;
+        for (uint32_t p = 0; p < m; p++) {
+            const rt_node &nd = nodes[order_of[p]];
+            if (nd.flags == RT_NODE_INTERNAL)
+                continue;
+            const bool inside = p < mesh_end;
+            fastbvh::Item it;
+            for (int k = 0; k < 3; k++) {
+                it.bmin[k] = nd.pmin[k];
+                it.bmax[k] = nd.pmax[k];
+            }
+            it.id = p;
+            if (nd.flags == RT_NODE_LEAF) {
+                (inside ? mesh_trees.back().items : top_items).push_back(it);
+            } else {
+                if (inside)
+                    return fail(ctx, RT_ERR_BAD_SCENE, "a mesh's inner tree may hold triangles only");
+                top_items.push_back(it);
+                if (nd.flags == RT_NODE_MESH) {
+                    mesh_of[p] = (uint32_t)mesh_trees.size();
+                    mesh_trees.emplace_back();
+                    mesh_end = p + size[p];
+                }
+            }
+        }
+    }
+    std::vector<fastbvh::Node> top_nodes;
+    fastbvh::build(top_items, top_nodes);
+    for (auto &tree : mesh_trees)
+        fastbvh::build(tree.items, tree.nodes);
+
+    // 4. Emit the fast tree, and with it the primitive arrays in fast-tree leaf order.
+    std::vector<float4> fn, tp, tn, sp, mt(2 * (size_t)n_mats);
     tp.reserve(3 * (size_t)n_tris);
     tn.reserve(3 * (size_t)n_tris);
-    uint32_t slot = 0;
-    for (uint32_t p = 0; p < m; p++) {
-        const uint32_t ni = order_of[p];
-        const rt_node &nd = nodes[ni];
-        uint32_t kind = nd.flags, ref = 0;
-        if (nd.flags == RT_NODE_LEAF) {
-            const rt_tri &t = tris[nd.left];
-            if (n_mats && t.mat >= n_mats)
-                return fail(ctx, RT_ERR_BAD_SCENE, "triangle material out of range");
-            ref = slot++;
-            // edges are the same fp32 subtractions the triangle test starts with (SimplifiedData.cpp:272-273)
-            const float e1x = t.pos[1][0] - t.pos[0][0], e1y = t.pos[1][1] - t.pos[0][1], e1z = t.pos[1][2] - t.pos[0][2];
-            const float e2x = t.pos[2][0] - t.pos[0][0], e2y = t.pos[2][1] - t.pos[0][1], e2z = t.pos[2][2] - t.pos[0][2];
-            tp.push_back(make_float4(t.pos[0][0], t.pos[0][1], t.pos[0][2], e1x));
-            tp.push_back(make_float4(e1y, e1z, e2x, e2y));
-            tp.push_back(make_float4(e2z, u2f(nd.left), u2f((uint32_t)t.mat), 0.f));
-            tn.push_back(make_float4(t.nrm[0][0], t.nrm[0][1], t.nrm[0][2], t.nrm[1][0]));
-            tn.push_back(make_float4(t.nrm[1][1], t.nrm[1][2], t.nrm[2][0], t.nrm[2][1]));
-            tn.push_back(make_float4(t.nrm[2][2], 0.f, 0.f, 0.f));
-        } else if (nd.flags == RT_NODE_SPHERE) {
-            ref = nd.left;
+    std::vector<uint32_t> slot_of(m, 0); // reference position of a leaf -> its triangle / sphere slot
+    uint32_t tri_slots = 0, sph_slots = 0;
+    auto push_node = [&](const float *bmin, const float *bmax, uint32_t skip_index, uint32_t word) {
+        fn.push_back(make_float4(bmin[0], bmin[1], bmin[2], bmax[0]));
+        fn.push_back(make_float4(bmax[1], bmax[2], u2f(skip_index * 32u), u2f(word)));
+    };
+    auto emit_tri = [&](uint32_t p) -> int { // p = reference position of the leaf
+        const rt_node &nd = nodes[order_of[p]];
+        const rt_tri &t = tris[nd.left];
+        if (n_mats && t.mat >= n_mats)
+            return RT_ERR_BAD_SCENE;
+        slot_of[p] = tri_slots++;
+        // edges are the same fp32 subtractions the triangle test starts with (SimplifiedData.cpp:272-273)
+        const float e1x = t.pos[1][0] - t.pos[0][0], e1y = t.pos[1][1] - t.pos[0][1], e1z = t.pos[1][2] - t.pos[0][2];
+        const float e2x = t.pos[2][0] - t.pos[0][0], e2y = t.pos[2][1] - t.pos[0][1], e2z = t.pos[2][2] - t.pos[0][2];
+        tp.push_back(make_float4(t.pos[0][0], t.pos[0][1], t.pos[0][2], e1x));
+        tp.push_back(make_float4(e1y, e1z, e2x, e2y));
+        tp.push_back(make_float4(e2z, u2f(nd.left), u2f((uint32_t)t.mat), u2f(p)));
+        tn.push_back(make_float4(t.nrm[0][0], t.nrm[0][1], t.nrm[0][2], t.nrm[1][0]));
+        tn.push_back(make_float4(t.nrm[1][1], t.nrm[1][2], t.nrm[2][0], t.nrm[2][1]));
+        tn.push_back(make_float4(t.nrm[2][2], 0.f, 0.f, 0.f));
+        return RT_OK;
+    };
+    const uint32_t n_top = (uint32_t)top_nodes.size();
+    std::vector<uint32_t> epos(n_top + 1, 0);
+    for (uint32_t q = 0; q < n_top; q++) {
+        const fastbvh::Node &fnode = top_nodes[q];
+        epos[q] = (uint32_t)(fn.size() / 2);
+        if (fnode.item == 0xFFFFFFFFu) {
+            push_node(fnode.bmin, fnode.bmax, 0u, KIND_INTERNAL); // skip is patched below
+            continue;
         }
+        const uint32_t p = top_items[fnode.item].id;
+        const rt_node &nd = nodes[order_of[p]];
+        if (nd.flags == RT_NODE_LEAF) {
+            if (emit_tri(p) != RT_OK)
+                return fail(ctx, RT_ERR_BAD_SCENE, "triangle material out of range");
+            push_node(fnode.bmin, fnode.bmax, 0u, (slot_of[p] << 3) | KIND_TRI);
+        } else if (nd.flags == RT_NODE_SPHERE) {
+            const rt_sphere &sph = spheres[nd.left];
+            if (sph.mat >= n_mats)
+                return fail(ctx, RT_ERR_BAD_SCENE, "sphere material out of range");
+            const uint32_t dielectric = mats[sph.mat].kind == RT_MAT_DIELECTRIC ? 1u : 0u;
+            slot_of[p] = sph_slots++;
+            sp.push_back(make_float4(sph.center[0], sph.center[1], sph.center[2], sph.radius));
+            sp.push_back(make_float4(u2f(sph.mat), u2f(sph.prim_id), u2f(dielectric), u2f(p)));
+            push_node(fnode.bmin, fnode.bmax, 0u, (slot_of[p] << 3) | KIND_SPHERE);
+        } else { // mesh object: its leaf record carries the leaf's reference position, its own tree follows
+            push_node(fnode.bmin, fnode.bmax, 0u, (p << 3) | KIND_MESH);
+            const MeshTree &tree = mesh_trees[mesh_of[p]];
+            const uint32_t base = (uint32_t)(fn.size() / 2);
+            for (uint32_t j = 0; j < (uint32_t)tree.nodes.size(); j++) {
+                const fastbvh::Node &in = tree.nodes[j];
+                uint32_t word = KIND_INTERNAL;
+                if (in.item != 0xFFFFFFFFu) {
+                    const uint32_t pj = tree.items[in.item].id;
+                    if (emit_tri(pj) != RT_OK)
+                        return fail(ctx, RT_ERR_BAD_SCENE, "triangle material out of range");
+                    word = (slot_of[pj] << 3) | KIND_TRI;
+                }
+                push_node(in.bmin, in.bmax, base + j + in.size, word);
+            }
+        }
+    }
+    const uint32_t n_fast = (uint32_t)(fn.size() / 2);
+    epos[n_top] = n_fast;
+    for (uint32_t q = 0; q < n_top; q++) // a top node's subtree ends where the next top node outside it starts
+        fn[2 * (size_t)epos[q] + 1].z = u2f(epos[q + top_nodes[q].size] * 32u);
+
+    // 5. The reference's own tree in its visiting order (the exact-order walks), sharing the primitive arrays.
+    std::vector<float4> dn(2 * (size_t)m + 2); // + the terminator record
+    for (uint32_t p = 0; p < m; p++) {
+        const rt_node &nd = nodes[order_of[p]];
+        const uint32_t kind = nd.flags;
+        const uint32_t ref = (nd.flags == RT_NODE_LEAF || nd.flags == RT_NODE_SPHERE) ? slot_of[p] : 0u;
         dn[2 * (size_t)p] = make_float4(nd.pmin[0], nd.pmin[1], nd.pmin[2], nd.pmax[0]);
         dn[2 * (size_t)p + 1] = make_float4(nd.pmax[1], nd.pmax[2], u2f((p + size[p]) * 32u), u2f((ref << 3) | kind));
     }
-    // terminator: a box no ray enters (NaN planes drop out of the slab test, closest <= FLT_MAX fails it), kind = all ones
+    // terminator: kind = all ones, never entered
     dn[2 * (size_t)m] = make_float4(1.f, 1.f, 1.f, -1.f);
     dn[2 * (size_t)m + 1] = make_float4(-1.f, -1.f, u2f(m * 32u), u2f(kNone));
     for (uint32_t i = 0; i < n_mats; i++) {
         mt[2 * (size_t)i] = make_float4(mats[i].albedo[0], mats[i].albedo[1], mats[i].albedo[2], mats[i].albedo[3]);
         mt[2 * (size_t)i + 1] = make_float4(u2f(mats[i].kind), mats[i].param, 0.f, 0.f);
     }
-    for (uint32_t i = 0; i < n_spheres; i++) {
-        if (spheres[i].mat >= n_mats)
-            return fail(ctx, RT_ERR_BAD_SCENE, "sphere material out of range");
-        const uint32_t dielectric = mats[spheres[i].mat].kind == RT_MAT_DIELECTRIC ? 1u : 0u;
-        sp[2 * (size_t)i] = make_float4(spheres[i].center[0], spheres[i].center[1], spheres[i].center[2], spheres[i].radius);
-        sp[2 * (size_t)i + 1] = make_float4(u2f(spheres[i].mat), u2f(spheres[i].prim_id), u2f(dielectric), 0.f);
-    }
 
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
     int rc;
-    if ((rc = upload(ctx, &ctx->d_nodes, dn)) != RT_OK || (rc = upload(ctx, &ctx->d_tri_pos, tp)) != RT_OK ||
+    if ((rc = upload(ctx, &ctx->d_nodes, dn)) != RT_OK || (rc = upload(ctx, &ctx->d_fnodes, fn)) != RT_OK ||
+        (rc = upload(ctx, &ctx->d_tri_pos, tp)) != RT_OK ||
         (rc = upload(ctx, &ctx->d_tri_nrm, tn)) != RT_OK || (rc = upload(ctx, &ctx->d_spheres, sp)) != RT_OK ||
         (rc = upload(ctx, &ctx->d_mats, mt)) != RT_OK) {
         free_scene(ctx);
@@ -1443,6 +1762,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_
         ctx->expected_visits = ra > 0.0 ? sum / ra : (double)m;
     }
     ctx->n_nodes = m;
+    ctx->n_fnodes = n_fast;
     ctx->has_scene = true;
     return RT_OK;
 }
@@ -1462,7 +1782,7 @@ int rt_set_options(rt_ctx *ctx, const rt_options *opt) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (opt->bounce_limit < 0 || opt->bounce_limit > kMaxLevels - 2 || opt->tile_world < 1 || opt->tile_rank < 0 || opt->tile_rank >= opt->tile_world ||
         (opt->estimator != RT_EST_SD_LOOP && opt->estimator != RT_EST_OLD_RECURSIVE) || opt->traversal < 0 ||
-        opt->traversal > RT_TRAV_NESTED)
+        opt->traversal > RT_TRAV_REFERENCE)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad options");
     ctx->opt = *opt;
     return RT_OK;

@@ -6,7 +6,7 @@ import numpy as np
 from . import _native as N
 
 EST_SD_LOOP, EST_OLD_RECURSIVE = 0, 1
-TRAV_AUTO, TRAV_LANE, TRAV_WAVE, TRAV_NESTED = 0, 1, 2, 3
+TRAV_AUTO, TRAV_LANE, TRAV_WAVE, TRAV_NESTED, TRAV_FAST, TRAV_FAST_REPLAY, TRAV_REFERENCE = 0, 1, 2, 3, 4, 5, 6
 MISS = 0xFFFFFFFF
 
 _STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_HIP", -4: "RT_ERR_NO_SCENE",
@@ -47,7 +47,7 @@ class Camera:
 class Stats:
     def __init__(self, c):
         self.rays, self.box_tests, self.tri_tests = c.rays, c.box_tests, c.tri_tests
-        self.sph_tests, self.tri_hits = c.sph_tests, c.tri_hits
+        self.sph_tests, self.tri_hits, self.replays = c.sph_tests, c.tri_hits, c.replays
         self.kernel_ms, self.total_ms = c.kernel_ms, c.total_ms
         self.kernel_ms_sum, self.launches = c.kernel_ms_sum, c.launches
 

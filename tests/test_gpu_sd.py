@@ -13,8 +13,21 @@ from helpers import O, R, WL, bits, oracle_camera, oracle_sd_scene, product_sd_s
 pytestmark = pytest.mark.gpu
 
 # every traversal variant must give the same bits: the wave-synchronous walk (scalar node fetches), the
-# per-lane walk, and the first-generation nested-loop kernel
-TRAVS = [R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED]
+# per-lane walk, the first-generation nested-loop kernel (these three perform the reference's own tests, so
+# their test counts equal the oracle's too), the fast walk over the device's own hierarchy, and the fast
+# walk with every ray forced through its ordered replay
+TRAVS = [R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED, R.TRAV_FAST, R.TRAV_FAST_REPLAY]
+REFERENCE_ORDER = (R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED)
+
+
+def check_counts(trav, st, ost):
+    assert (st.rays, st.tri_hits) == (ost.rays, ost.tri_hits)
+    if trav in REFERENCE_ORDER:
+        assert (st.box_tests, st.tri_tests) == (ost.box_tests, ost.tri_tests)
+    else:
+        assert 0 < st.box_tests and 0 < st.tri_tests
+        if trav == R.TRAV_FAST_REPLAY:
+            assert st.replays >= st.tri_hits  # every ray with a candidate went through the replay
 
 
 @pytest.fixture(scope="module")
@@ -40,7 +53,7 @@ def test_primary_ids_dragon2426_400x225(tracer, dragon2426, trav):
     oimg, oprim, ost = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, 400, 225, 1, 1, want_primary=True)
     assert (prim != R.MISS).sum() > 1000
     assert np.count_nonzero(prim != oprim) == 0
-    assert (st.rays, st.box_tests, st.tri_tests, st.tri_hits) == (ost.rays, ost.box_tests, ost.tri_tests, ost.tri_hits)
+    check_counts(trav, st, ost)
     assert np.array_equal(bits(img), bits(oimg))
 
 
@@ -66,7 +79,7 @@ def test_shaded_image_bit_exact(tracer, dragon2426, trav):
     img, _, st = tracer.trace(320, 180, 1, 8)
     opt = O.make_options(bounce_limit=8, seed=7, jitter=0.001, trig=O.TRIG_POLY)
     oimg, _, ost = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, 320, 180, 1, 8)
-    assert (st.rays, st.box_tests, st.tri_tests) == (ost.rays, ost.box_tests, ost.tri_tests)
+    check_counts(trav, st, ost)
     assert np.array_equal(bits(img), bits(oimg))
     # against libm cos/sin: the stated per-pixel tolerance
     opt.trig = O.TRIG_LIBM
@@ -120,7 +133,7 @@ def test_dragon18520_small(tracer, trav):
     opt = O.make_options(bounce_limit=8, seed=1, trig=O.TRIG_POLY)
     oimg, oprim, ost = os_.render(oracle_camera(WL.DRAGON_18520_CAMERA), opt, 240, 135, 1, 2, want_primary=True)
     assert np.count_nonzero(prim != oprim) == 0
-    assert (st.rays, st.box_tests, st.tri_tests) == (ost.rays, ost.box_tests, ost.tri_tests)
+    check_counts(trav, st, ost)
     assert np.array_equal(bits(img), bits(oimg))
 
 

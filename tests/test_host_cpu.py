@@ -108,7 +108,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.rt_version().decode().endswith("gfx950")
     assert C.sizeof(N.Node) == 36 and C.sizeof(N.Tri) == 100          # == sizeof(sd::Node), sizeof(sd::Triangle)
     assert N.Node.flags.offset == 32 and N.Tri.mat.offset == 96
-    assert C.sizeof(N.CameraC) == 40 and C.sizeof(N.OptionsC) == 36 and C.sizeof(N.StatsC) == 56
+    assert C.sizeof(N.CameraC) == 40 and C.sizeof(N.OptionsC) == 36 and C.sizeof(N.StatsC) == 64
 
 
 def test_kernels_are_compiled_for_gfx950_without_fma_contraction():

@@ -30,5 +30,5 @@ t.set_options(bounce_limit=a.bounce or wl.bounce_limit, estimator=wl.estimator, 
 for i in range(a.reps):
     _, _, st = t.trace(W, H, 1, spp, want_image=a.image)
     print(f"{a.workload} {W}x{H} spp={spp} rep={i}: rays={st.rays} kernel_ms={st.kernel_ms:.3f} "
-          f"Mrays/s={st.rays / st.kernel_ms / 1e3:.2f} total_ms={st.total_ms:.3f} box={st.box_tests} tri={st.tri_tests} sph={st.sph_tests}", flush=True)
+          f"Mrays/s={st.rays / st.kernel_ms / 1e3:.2f} total_ms={st.total_ms:.3f} box={st.box_tests} tri={st.tri_tests} sph={st.sph_tests} replays={st.replays}", flush=True)
 t.close()
