@@ -22,7 +22,7 @@ VALU_PEAK_TOPS = 78.6         # 256 CU x 128 lanes x 2.4 GHz, one op per lane-cy
 
 def cpu_baseline(wl, args):
     """Times the CPU oracle (a port of the reference path) on a bounded sample of the workload: the same
-    scene, camera and bounce limit at reduced resolution and 1 spp."""
+    scene, camera and bounce limit at reduced resolution and a few spp (about 10-20 s of CPU work)."""
     from oracle import objparse, oracle as O
     from raytracing_amd import workloads as WL
     import raytracing_amd as R
@@ -48,13 +48,13 @@ def cpu_baseline(wl, args):
     # trig evaluations per bounce is negligible next to the traversal)
     opt = O.make_options(bounce_limit=wl.bounce_limit, seed=wl.seed, jitter=wl.jitter, trig=O.TRIG_POLY,
                          threads=threads, lock_per_pixel=0, accum=O.ACCUM_FORWARD)
-    _, _, st = osc.render(ocam, opt, w, h, 1, 1)
+    _, _, st = osc.render(ocam, opt, w, h, 1, args.cpu_spp)
     # (i) the reference's own schedule: 16 row bands per sample and a shared_lock per pixel
     opt_ref = O.make_options(bounce_limit=wl.bounce_limit, seed=wl.seed, jitter=wl.jitter, trig=O.TRIG_LIBM,
                              threads=16, lock_per_pixel=1, accum=O.ACCUM_RECURSIVE)
-    _, _, st_ref = osc.render(ocam, opt_ref, w, h, 1, 1)
+    _, _, st_ref = osc.render(ocam, opt_ref, w, h, 1, args.cpu_spp)
     return {"value": st.rays / st.seconds / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{wl.name} scene/camera/bounce limit at {w}x{h}, 1 spp ({st.rays} rays, {st.seconds:.2f} s)",
+            "sample": f"{wl.name} scene/camera/bounce limit at {w}x{h}, {args.cpu_spp} spp ({st.rays} rays, {st.seconds:.2f} s)",
             "reference_schedule_value": st_ref.rays / st_ref.seconds / 1e6,
             "reference_schedule": "16 std::async row bands + shared_lock per pixel"}, st, (w, h)
 
@@ -67,7 +67,10 @@ def main():
     ap.add_argument("--workload", default="dragon18520_1080p")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (0 = the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-div", type=int, default=4, help="cpu_baseline sample: resolution divisor")
+    ap.add_argument("--no-reference-counts", action="store_true",
+                    help="skip the untimed pass that counts the tests of the reference-order walk")
+    ap.add_argument("--cpu-div", type=int, default=2, help="cpu_baseline sample: resolution divisor")
+    ap.add_argument("--cpu-spp", type=int, default=3, help="cpu_baseline sample: samples per pixel")
     args = ap.parse_args()
 
     import numpy as np
@@ -99,18 +102,26 @@ def main():
     tr.set_stream(torch.cuda.current_stream().cuda_stream)
     img = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
 
-    def options(stats):
+    def options(stats, traversal=R.TRAV_FAST):
         tr.set_options(bounce_limit=wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
-                       collect_stats=stats, sample_offset=P.sample_offset(rank, spp))
+                       collect_stats=stats, sample_offset=P.sample_offset(rank, spp), traversal=traversal)
 
     def step():
         tr.trace_device(W, H, 1, spp, img.data_ptr())
         P.combine_sample_split(img, dst=0)  # N > 1: one RCCL reduce(SUM) of the per-rank means, / world on rank 0
 
-    # algorithmic work of one launch: counted once, untimed, by the counting variant of the same kernel
+    # work of one trace call: counted once, untimed, by the counting variant of the same kernel
     options(True)
     tr.trace_device(W, H, 1, spp, img.data_ptr())
     counts = tr.sync()
+    # the same rays walked in the reference's own visiting order over the reference's own boxes: what the
+    # reference traversal (and the CPU baseline) has to do for this frame
+    ref_counts = None
+    if rank == 0 and not args.no_reference_counts:
+        options(True, R.TRAV_REFERENCE)
+        tr.trace_device(W, H, 1, spp, img.data_ptr())
+        ref_counts = tr.sync()
+        assert ref_counts.rays == counts.rays and ref_counts.tri_hits == counts.tri_hits
     options(False)
 
     for _ in range(args.warmup):
@@ -140,17 +151,25 @@ def main():
 
     if rank == 0:
         kernel_ms = st.kernel_ms_sum / st.launches
-        # 32 B per slab test (box + 2 indices), 36 B per triangle test (3 positions), 16 B per sphere test,
-        # 36 B of normals per traversal that ends on a triangle, 16 B per pixel for the mean that is written
-        alg_bytes = 32 * counts.box_tests + 36 * counts.tri_tests + 16 * counts.sph_tests + 36 * counts.tri_hits \
-            + 16 * W * H
-        alg_ops = 27 * counts.box_tests + 56 * counts.tri_tests + 24 * counts.sph_tests + 60 * counts.rays
+
+        def traversal_bytes(c):
+            # 32 B per slab test (box + 2 links), 36 B per triangle test (3 positions), 16 B per sphere test,
+            # 36 B of normals per traversal that ends on a triangle
+            return 32 * c.box_tests + 36 * c.tri_tests + 16 * c.sph_tests + 36 * c.tri_hits
+
+        def traversal_ops(c):
+            return 27 * c.box_tests + 56 * c.tri_tests + 24 * c.sph_tests + 60 * c.rays
+
+        # per pixel sample: one 16 B colour written and read once (the fold); per pixel: the 16 B mean written
+        image_bytes = 32 * W * H * spp + 16 * W * H
+        alg_bytes = traversal_bytes(counts) + image_bytes
+        alg_ops = traversal_ops(counts)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh).get(f"{wl.name}:{spp}")
+                traffic = json.load(fh).get(f"{wl.name}:{spp}:fast")
         out = {
             "metric": "Mrays/s (all bounces)", "value": rays_total / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -159,27 +178,37 @@ def main():
                     if wl.estimator == R.EST_SD_LOOP else "synthetic",
             "config": {"workload": wl.name, "width": W, "height": H, "spp_per_step_per_gpu": spp,
                        "bounce_limit": wl.bounce_limit, "rays_per_step_per_gpu": int(st.rays),
-                       "traversal": "reference visiting order (bit-exact)",
+                       "traversal": "fast walk (own hierarchy over the reference's leaf boxes; hits bit-identical "
+                                    "to the reference-order walk)",
                        "parallelism": "scene replicated, sample-index range per GPU, one RCCL reduce per step"
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_trace", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "note": "scene (<= 2.4 MB) is L2-resident, so algorithmic bytes are served by L1/L2 and can "
-                                 "exceed the HBM peak; the binding roof is VALU issue, see 'valu'"},
+                         "kernel": "k_path (one launch per bounce level) + k_fold = one trace call",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "note": "algorithmic bytes = the tests this walk performs x their record payload + the "
+                                 "per-sample colour traffic; node and triangle records are L2-resident for this "
+                                 "scene, so most of these bytes never reach HBM (see traffic)"},
             "valu": {"achieved": alg_ops / (kernel_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS, "unit": "Tops/s",
                      "frac": alg_ops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
                      "algorithmic_ops_per_launch": int(alg_ops)},
             "counts_per_launch": {"rays": int(counts.rays), "box_tests": int(counts.box_tests),
                                   "tri_tests": int(counts.tri_tests), "sph_tests": int(counts.sph_tests),
-                                  "tri_hits": int(counts.tri_hits)},
+                                  "tri_hits": int(counts.tri_hits), "replays": int(counts.replays)},
         }
+        if ref_counts is not None:
+            rb = traversal_bytes(ref_counts) + 16 * W * H
+            out["reference_order_equivalent"] = {
+                "box_tests": int(ref_counts.box_tests), "tri_tests": int(ref_counts.tri_tests),
+                "sph_tests": int(ref_counts.sph_tests), "algorithmic_bytes_per_launch": int(rb),
+                "equivalent_GBps": rb / (kernel_ms * 1e-3) / 1e9,
+                "note": "tests and bytes the reference's own traversal needs for the same rays and the same hits"}
         if world == 1 and not args.no_cpu_baseline:
             cb, ost, (cw, ch) = cpu_baseline(wl, args)
             # same bounded sample on the GPU: counts must equal the oracle's (checker, not the thing measured)
             tr.set_options(bounce_limit=wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
-                           collect_stats=True)
-            _, _, gst = tr.trace(cw, ch, 1, 1, want_image=False)
+                           collect_stats=True, traversal=R.TRAV_REFERENCE)
+            _, _, gst = tr.trace(cw, ch, 1, args.cpu_spp, want_image=False)
             cb["gpu_counts_match_oracle"] = bool((gst.rays, gst.box_tests, gst.tri_tests, gst.sph_tests) ==
                                                  (ost.rays, ost.box_tests, ost.tri_tests, ost.sph_tests))
             out["cpu_baseline"] = cb

@@ -892,7 +892,7 @@ struct Path {
 // Wavefront path kernel: one launch per bounce level.
 //
 // Level 0 generates the camera rays of `S` consecutive samples of every pixel this context owns.  A
-// wave takes 64 work items at a time from an atomic cursor; items are numbered (tile, sample, pixel in
+// wave takes 64 work items at a time; items are numbered (tile, sample, pixel in
 // the 8x8 tile), so the 64 rays of a batch are the camera rays of one tile for one sample and stay
 // coherent.  After the closest-hit search a path either ENDS -- its colour is stored in the per-sample
 // colour buffer, colors[sample][pixel] -- or CONTINUES: its state is appended to the queue of the next
@@ -909,13 +909,14 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
     // A level with too few rays to fill the chip is bound by the latency of one walk, which is shortest
     // when every lane walks alone; a level that saturates the chip is bound by throughput.
     const bool use_wave = WALK == WALK_WAVE && n_in >= P.wave_min_rays;
-    for (;;) {
-        unsigned int base = 0;
-        if (lane == 0)
-            base = atomicAdd(P.cursor, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n_in)
-            break;
+    // Batches of 64 items are dealt to the waves round-robin: one shared cursor would be hit by half a million
+    // same-address atomics per launch at level 0, which alone takes longer than the rays.  Neighbouring
+    // batches (the samples of one tile, tiles of one image row) go to different waves, so the expensive part of
+    // the image is spread over the whole grid.
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (uint64_t base64 = (uint64_t)wave_id * 64u; base64 < n_in; base64 += (uint64_t)n_waves * 64u) {
+        const uint32_t base = (uint32_t)base64;
         const uint32_t g = base + lane;
         bool live = g < n_in;
         Path path;
