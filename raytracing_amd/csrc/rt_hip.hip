@@ -1125,12 +1125,16 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
             }
         }
     }
+    // Counters: one atomic per wave that has something to add.  (Thousands of same-address atomics are
+    // serialised by the memory system; a launch whose level is empty must not pay for them.)
+    if (n_in == 0u)
+        return;
     unsigned long long r = wave_sum(cnt.rays);
-    if (lane == 0)
+    if (lane == 0 && r != 0ull)
         atomicAdd(&P.counters[0], r);
     if (STATS) {
         unsigned long long b = wave_sum(cnt.box), t = wave_sum(cnt.tri), s = wave_sum(cnt.sph), h = wave_sum(cnt.trih);
-        if (lane == 0) {
+        if (lane == 0 && r != 0ull) {
             atomicAdd(&P.counters[1], b);
             atomicAdd(&P.counters[2], t);
             atomicAdd(&P.counters[3], s);
@@ -1253,6 +1257,13 @@ template <class T> int upload(rt_ctx *ctx, float4 **dst, const std::vector<T> &s
 
 template <int KERNEL, bool OLD, bool STATS> int occupancy(int *out) {
     int n = 0;
+    if (KERNEL != 0) {
+        // k_path deals its batches round-robin over whatever grid it is given, so the grid only has to be large
+        // enough to fill the chip: 8 blocks of 4 waves per CU is the hardware's limit of 8 waves per SIMD.  Blocks
+        // that are not resident at once simply start as others finish.
+        *out = 8;
+        return 0;
+    }
     hipError_t e = KERNEL == 3   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, WALK_FAST>, 256, 0)
                    : KERNEL == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, WALK_WAVE>, 256, 0)
                    : KERNEL == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, WALK_LANE>, 256, 0)

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Per-launch view of the counter CSVs written by tools/pmc_passes.sh: one row per k_path / k_fold launch of the
+traced call, one column per counter."""
+import csv
+import glob
+import sys
+
+table = {}  # dispatch order -> {counter: value}
+names = {}
+for path in sorted(glob.glob(sys.argv[1] + "/*/*/*_counter_collection.csv")):
+    with open(path) as fh:
+        rows = [r for r in csv.DictReader(fh) if any(k in r["Kernel_Name"] for k in ("k_trace", "k_path", "k_fold"))]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+    rank = {d: i for i, d in enumerate(ids)}
+    for r in rows:
+        i = rank[int(r["Dispatch_Id"])]
+        table.setdefault(i, {})
+        table[i][r["Counter_Name"]] = table[i].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        names[i] = r["Kernel_Name"][-40:]
+cols = sorted({c for t in table.values() for c in t})
+print("launch," + ",".join(cols))
+for i in sorted(table):
+    print(f"{i}," + ",".join(f"{table[i].get(c, 0):.4g}" for c in cols))
