@@ -61,6 +61,7 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kSphereBit = 0x80000000u;
 constexpr uint32_t KIND_INTERNAL = 0, KIND_TRI = 1, KIND_MESH = 2, KIND_SPHERE = 4;
 constexpr int kMaxLevels = 64;             // bounce levels a wavefront trace can launch (bounce_limit <= 62)
+constexpr int kTailLevel = 3;               // from this bounce level on, one launch follows every remaining path to its end
 constexpr int kChunkSamples = 16;          // samples per pixel traced per wavefront chunk
 constexpr size_t kMaxItems = 48u << 20;    // work items (pixel samples) per chunk: bounds the queue workspace
 
@@ -78,6 +79,7 @@ struct KParams {
     unsigned long long *counters; // rays, box, tri, sph, tri_hits, replays
     uint32_t n_nodes;
     uint32_t n_fnodes;
+    int tail;         // k_path: follow every path of this launch to its end instead of queueing the next bounce
     int force_replay; // fast walk: resolve every ray by the ordered replay (verification aid)
     uint32_t n_my_tiles;
     int W, H, tiles_x;
@@ -973,8 +975,13 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
                 path.depth = (int)__float_as_uint(r3.y);
             }
         }
+        bool ended = false;
+        // One pass = one closest-hit search and its shading.  In tail mode (the deep levels, whose few rays cannot
+        // fill the chip and whose launches each last as long as their single longest walk) a lane keeps its path
+        // until it ends, instead of handing it to another launch.
+        for (;;) {
         if (__ballot(live) == 0ull)
-            continue;
+            break;
         path.inv = mk3(1.0f / path.d.x, 1.0f / path.d.y, 1.0f / path.d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
         // ---- one closest-hit search per lane ----
         Best hit;
@@ -994,7 +1001,7 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
             }
         }
         // ---- shade: the path ends with a colour or continues with a new ray ----
-        bool ended = false;
+        ended = false;
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) {
             const uint32_t dim = 3u + 4u * (uint32_t)path.depth;
@@ -1108,6 +1115,12 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
             if (ended)
                 P.colors[cidx] = c;
         }
+        if (P.tail == 0)
+            break;
+        live = live && !ended;
+        }
+        if (P.tail != 0)
+            continue;
         // ---- continuing paths go to the next level's queue, compacted per wave ----
         const bool cont = live && !ended;
         const unsigned long long cmask = __ballot(cont);
@@ -1404,6 +1417,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         P.n_items = (uint32_t)((size_t)s_now * items_per_sample);
         for (int level = 0; level < levels; level++) {
             P.level = level;
+            P.tail = (level >= kTailLevel || level == levels - 1) ? 1 : 0;
             P.q_in = ctx->d_q[level & 1];
             P.q_out = ctx->d_q[(level + 1) & 1];
             P.cursor = ctx->d_levels + level;
@@ -1431,6 +1445,8 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
             }
 #undef RT_LAUNCH_PATH
             RT_HIP_CHECK(ctx, hipGetLastError());
+            if (P.tail)
+                break;
         }
         hipLaunchKernelGGL(k_fold, dim3((unsigned)((npix + 255) / 256)), block, 0, ctx->stream, d_img, ctx->d_colors,
                            (uint32_t)npix, W, P.tiles_x, o.tile_rank, o.tile_world, P.chunk_first, s_now);
