@@ -33,9 +33,10 @@ def cpu_baseline(wl, args):
     ocam = O.make_camera(cam.focal_length, cam.position, cam.look_at, cam.width, cam.aspect_ratio)
     if wl.estimator == R.EST_SD_LOOP:
         osc = O.SdScene()
-        path = {"dragon18520_1080p": WL.DRAGON_18520, "dragon18520_4k": WL.DRAGON_18520,
-                "dragon2426_1080p": WL.DRAGON_2426}[wl.name]
-        tris, sizes = objparse.load_obj(path)
+        tris, sizes = objparse.load_obj(wl.obj_path)
+        if wl.field_k:
+            tris = WL.dragon_grid_tris(tris, wl.field_k)
+            sizes = [len(tris)]
         osc.add_model(tris, sizes)
         osc.finalize()
     else:
@@ -117,7 +118,8 @@ def main():
     # the same rays walked in the reference's own visiting order over the reference's own boxes: what the
     # reference traversal (and the CPU baseline) has to do for this frame
     ref_counts = None
-    if rank == 0 and not args.no_reference_counts:
+    # (skipped for scenes where that walk would take minutes: the million-triangle fields)
+    if rank == 0 and not args.no_reference_counts and len(wl.scene.nodes()) < 200000:
         options(True, R.TRAV_REFERENCE)
         tr.trace_device(W, H, 1, spp, img.data_ptr())
         ref_counts = tr.sync()

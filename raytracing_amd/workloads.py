@@ -98,23 +98,61 @@ def dragon_grid_tris(tris24, k, spacing=0.25):
 
 
 class Workload:
-    def __init__(self, name, scene, camera, estimator, width, height, spp, bounce_limit, seed=1, jitter=0.001):
+    def __init__(self, name, scene, camera, estimator, width, height, spp, bounce_limit, seed=1, jitter=0.001,
+                 obj_path=None, field_k=0):
         self.name, self.scene, self.camera, self.estimator = name, scene, camera, estimator
         self.width, self.height, self.spp, self.bounce_limit = width, height, spp, bounce_limit
         self.seed, self.jitter = seed, jitter
+        # how a checker rebuilds the same scene: the OBJ file, and the side of the grid of copies (0 = the file as is)
+        self.obj_path, self.field_k = obj_path, field_k
+
+
+def field_camera(k, spacing=0.25):
+    """Looks down at the k x k dragon field from in front of it."""
+    half = np.float32(spacing * (k - 1) / 2)
+    c = (float(half) - 0.006, 0.07, -0.915 + float(half))
+    s = 0.9 * spacing * k
+    return Camera(2.0, (c[0], c[1] + 0.55 * s, c[2] + 1.0 * s), 2.0, 16.0 / 9.0, c)
+
+
+def _load_obj_tris(path):
+    """Triangle soup (n, 24) of an OBJ file through the product's own reader (csrc/host/obj_reader.cpp)."""
+    sc = SdScene().load_obj(path).finalize()
+    t = sc.tris()
+    out = np.zeros((len(t), 3, 8), dtype=np.float32)
+    out[:, :, 0:3] = t["pos"]
+    out[:, :, 3:6] = t["nrm"]
+    out[:, :, 6:8] = t["uv"]
+    return out.reshape(-1, 24)
+
+
+def dragon_field(name, k, width, height, spp):
+    """k x k copies of the 18520-triangle dragon flattened into one triangle list (k = 8: 1.19 M triangles,
+    k = 23: 9.8 M), one flat-array scene under the reference's median-split BVH."""
+    tris = dragon_grid_tris(_load_obj_tris(DRAGON_18520), k)
+    sc = SdScene().add_model(tris).finalize()
+    return Workload(name, sc, field_camera(k), EST_SD_LOOP, width, height, spp, 8, obj_path=DRAGON_18520, field_k=k)
 
 
 def make_workload(name):
     """Workloads named after the configurations they realise."""
     if name == "dragon18520_1080p":  # the headline: 18520-triangle Stanford Dragon, 1080p
         sc = SdScene().load_obj(DRAGON_18520).finalize()
-        return Workload(name, sc, DRAGON_18520_CAMERA, EST_SD_LOOP, 1920, 1080, 16, 8)
+        return Workload(name, sc, DRAGON_18520_CAMERA, EST_SD_LOOP, 1920, 1080, 16, 8, obj_path=DRAGON_18520)
     if name == "dragon2426_1080p":
         sc = SdScene().load_obj(DRAGON_2426).finalize()
-        return Workload(name, sc, DRAGON_2426_CAMERA, EST_SD_LOOP, 1920, 1080, 16, 8)
+        return Workload(name, sc, DRAGON_2426_CAMERA, EST_SD_LOOP, 1920, 1080, 16, 8, obj_path=DRAGON_2426)
     if name == "dragon18520_4k":
         sc = SdScene().load_obj(DRAGON_18520).finalize()
-        return Workload(name, sc, DRAGON_18520_CAMERA, EST_SD_LOOP, 3840, 2160, 256, 8)
+        return Workload(name, sc, DRAGON_18520_CAMERA, EST_SD_LOOP, 3840, 2160, 256, 8, obj_path=DRAGON_18520)
+    if name == "dragon_field_k8_1080p":   # 1.19 M triangles
+        return dragon_field(name, 8, 1920, 1080, 16)
+    if name == "dragon_field_k8_4k":
+        return dragon_field(name, 8, 3840, 2160, 1024)
+    if name == "dragon_field_k23_4k":     # 9.8 M triangles: node and triangle records no longer fit the L2
+        return dragon_field(name, 23, 3840, 2160, 1024)
+    if name == "dragon_field_k23_1080p":
+        return dragon_field(name, 23, 1920, 1080, 16)
     if name == "rtiow_1080p":
         sc = build_old_scene(rtiow_spheres()).build()
         return Workload(name, sc, RTIOW_CAMERA, EST_OLD_RECURSIVE, 1920, 1080, 64, 8, seed=42)

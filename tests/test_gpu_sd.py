@@ -8,7 +8,7 @@ of the pixels.
 import numpy as np
 import pytest
 
-from helpers import O, R, WL, bits, oracle_camera, oracle_sd_scene, product_sd_scene, psnr
+from helpers import O, R, WL, bits, objparse, oracle_camera, oracle_sd_scene, product_sd_scene, psnr
 
 pytestmark = pytest.mark.gpu
 
@@ -135,6 +135,48 @@ def test_dragon18520_small(tracer, trav):
     assert np.count_nonzero(prim != oprim) == 0
     check_counts(trav, st, ost)
     assert np.array_equal(bits(img), bits(oimg))
+
+
+@pytest.mark.parametrize("trav", [R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_LANE])
+def test_dragon_field_k2(tracer, trav):
+    """A 2 x 2 grid of translated dragon copies flattened into one triangle list (the small case of the
+    instanced dragon field), looked at along the rows so that rays cross several copies."""
+    tris, _ = objparse.load_obj(WL.DRAGON_2426)
+    grid = WL.dragon_grid_tris(tris, 2)
+    ps = R.SdScene().add_model(grid).finalize()
+    os_ = O.SdScene()
+    os_.add_model(grid, [len(grid)])
+    os_.finalize()
+    tracer.upload(ps)
+    for cam in (R.Camera(1.0, (0.12, 0.5, 0.9), 2.0, 16.0 / 9.0, (0.12, 0.07, 0.11)),
+                R.Camera(1.0, (-0.3, 0.08, 0.0), 2.0, 16.0 / 9.0, (0.3, 0.06, 0.0))):
+        tracer.set_camera(cam)
+        tracer.set_options(bounce_limit=8, seed=11, collect_stats=True, traversal=trav)
+        img, prim, st = tracer.trace(256, 144, 1, 2, want_primary=True)
+        opt = O.make_options(bounce_limit=8, seed=11, trig=O.TRIG_POLY)
+        oimg, oprim, ost = os_.render(oracle_camera(cam), opt, 256, 144, 1, 2, want_primary=True)
+        assert (prim != R.MISS).sum() > 500
+        assert np.count_nonzero(prim != oprim) == 0
+        check_counts(trav, st, ost)
+        assert np.array_equal(bits(img), bits(oimg))
+
+
+def test_full_size_properties_fast_vs_reference_order(tracer):
+    """At the benchmark's full size the oracle is too slow to be the checker; the two device walks are
+    independent implementations of the same contract, so their images must agree bit for bit."""
+    ps = product_sd_scene([WL.DRAGON_18520])
+    tracer.upload(ps)
+    tracer.set_camera(WL.DRAGON_18520_CAMERA)
+    out = {}
+    for trav in (R.TRAV_FAST, R.TRAV_WAVE):
+        tracer.set_options(bounce_limit=8, seed=1, traversal=trav)
+        out[trav] = tracer.trace(1920, 1080, 1, 2, want_primary=True)
+    (fi, fp, fs), (wi, wp, ws) = out[R.TRAV_FAST], out[R.TRAV_WAVE]
+    assert fs.rays == ws.rays
+    assert np.array_equal(fp, wp)
+    assert np.array_equal(bits(fi), bits(wi))
+    # alpha = fraction of samples that escaped to the sky, in [0, 1]; colours are finite and non-negative
+    assert np.isfinite(fi).all() and fi.min() >= 0.0 and fi[..., 3].max() <= 1.0
 
 
 def test_errors(tracer):

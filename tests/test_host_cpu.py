@@ -146,3 +146,27 @@ def test_product_does_not_touch_the_oracle():
     for lib in (N.HIP_LIB_PATH, N.HOST_LIB_PATH):
         deps = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
         assert "oracle" not in deps
+
+
+def test_image_writer_gamma_and_row_order(tmp_path):
+    """PNG/PPM output = the reference's display path: pow(rgb, 1/2.2) (GLSL/postProcess.fs:26), clamp, row 0 at
+    the bottom."""
+    import zlib
+    from raytracing_amd import imageio
+    img = np.zeros((2, 3, 4), dtype=np.float32)
+    img[0, :, :3] = 0.5          # bottom row
+    img[1, 0, :3] = (2.0, 0.0, 1.0)
+    px = imageio.to_display(img)
+    assert px.shape == (2, 3, 3)
+    assert tuple(px[0, 0]) == (255, 0, 255)          # top row of the file = row 1 of the image, clamped
+    assert px[1, 0, 0] == int(0.5 ** (1 / 2.2) * 255.0 + 0.5)
+    ppm, png = tmp_path / "a.ppm", tmp_path / "a.png"
+    imageio.write_ppm(str(ppm), img)
+    imageio.write_png(str(png), img)
+    raw = ppm.read_bytes()
+    assert raw.startswith(b"P6\n3 2\n255\n") and raw[11:] == px.tobytes()
+    data = png.read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    idat = data[data.index(b"IDAT") + 4:data.index(b"IEND") - 8]
+    rows = zlib.decompress(idat)
+    assert rows == b"".join(b"\x00" + px[y].tobytes() for y in range(2))
