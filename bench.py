@@ -28,7 +28,7 @@ def cpu_baseline(wl, args):
     import raytracing_amd as R
     threads = min(os.cpu_count() or 1, 16)
     div = args.cpu_div
-    w, h = wl.width // div, wl.height // div
+    w, h = max(wl.width // div, 16), max(wl.height // div, 9)
     cam = wl.camera
     ocam = O.make_camera(cam.focal_length, cam.position, cam.look_at, cam.width, cam.aspect_ratio)
     if wl.estimator == R.EST_SD_LOOP:
@@ -49,11 +49,16 @@ def cpu_baseline(wl, args):
     # trig evaluations per bounce is negligible next to the traversal)
     opt = O.make_options(bounce_limit=wl.bounce_limit, seed=wl.seed, jitter=wl.jitter, trig=O.TRIG_POLY,
                          threads=threads, lock_per_pixel=0, accum=O.ACCUM_FORWARD)
-    _, _, st = osc.render(ocam, opt, w, h, 1, args.cpu_spp)
+    # the sample is sized from a 1-spp probe so that each of the two timed renders is about args.cpu_seconds of
+    # CPU work whatever the workload costs per ray
+    _, _, probe = osc.render(ocam, opt, w, h, 1, 1)
+    spp = args.cpu_spp or int(min(max(args.cpu_seconds / max(probe.seconds, 1e-4), 1), 256))
+    args.cpu_spp = spp
+    _, _, st = osc.render(ocam, opt, w, h, 1, spp)
     # (i) the reference's own schedule: 16 row bands per sample and a shared_lock per pixel
     opt_ref = O.make_options(bounce_limit=wl.bounce_limit, seed=wl.seed, jitter=wl.jitter, trig=O.TRIG_LIBM,
                              threads=16, lock_per_pixel=1, accum=O.ACCUM_RECURSIVE)
-    _, _, st_ref = osc.render(ocam, opt_ref, w, h, 1, args.cpu_spp)
+    _, _, st_ref = osc.render(ocam, opt_ref, w, h, 1, spp)
     return {"value": st.rays / st.seconds / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{wl.name} scene/camera/bounce limit at {w}x{h}, {args.cpu_spp} spp ({st.rays} rays, {st.seconds:.2f} s)",
             "reference_schedule_value": st_ref.rays / st_ref.seconds / 1e6,
@@ -70,8 +75,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-counts", action="store_true",
                     help="skip the untimed pass that counts the tests of the reference-order walk")
-    ap.add_argument("--cpu-div", type=int, default=2, help="cpu_baseline sample: resolution divisor")
-    ap.add_argument("--cpu-spp", type=int, default=3, help="cpu_baseline sample: samples per pixel")
+    ap.add_argument("--cpu-div", type=int, default=4, help="cpu_baseline sample: resolution divisor")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="cpu_baseline sample: samples per pixel (0 = sized from a probe)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="cpu_baseline sample: target seconds per timed render")
     args = ap.parse_args()
 
     import numpy as np
