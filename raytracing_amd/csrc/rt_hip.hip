@@ -60,6 +60,8 @@ RT_HD f3 basis_mul(f3 c0, f3 c1, f3 c2, f3 v) {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kSphereBit = 0x80000000u;
 constexpr uint32_t KIND_INTERNAL = 0, KIND_TRI = 1, KIND_MESH = 2, KIND_SPHERE = 4;
+constexpr int kSubQueues = 64;             // a level's path queue is 64 sub-queues, each with its own append counter
+constexpr int kCounterSlots = 64, kCounterStride = 16; // statistics are added into 64 slots of 16 values, summed by the host
 constexpr int kMaxLevels = 64;             // bounce levels a wavefront trace can launch (bounce_limit <= 62)
 constexpr int kTailLevel = 3;               // from this bounce level on, one launch follows every remaining path to its end
 constexpr int kChunkSamples = 16;          // samples per pixel traced per wavefront chunk
@@ -94,9 +96,9 @@ struct KParams {
     const float4 *q_in;         // path records of this level (4 x float4 each)
     float4 *q_out;              // path records of the next level
     float4 *colors;             // colors[sample in chunk][pixel]
-    unsigned int *cursor;       // work cursor of this level
-    const unsigned int *n_in;   // record count of this level (levels > 0)
-    unsigned int *n_out;        // append counter of the next level
+    const unsigned int *sub_in; // levels > 0: record counts of this level's sub-queues (one per 128 bytes)
+    unsigned int *sub_out;      // append counters of the next level's sub-queues
+    uint32_t sub_cap;           // records a sub-queue can hold; sub-queue q starts at record q * sub_cap
     uint32_t n_items;           // level 0: n_my_tiles * 64 * S
     uint32_t npix;
     int level, S, chunk_first;
@@ -423,6 +425,11 @@ RT_D float4 sample_old(const KParams &P, RayState ray, uint32_t key, Cnt &cnt, u
     }
 }
 
+// Thousands of atomics on ONE address are serialised by the memory system (about 10 ns each: 80 us for one per
+// wave of a full grid), so counters and queue appends are spread over 64 addresses in separate cache lines.
+RT_D unsigned long long *counter_slot(const KParams &P, uint32_t wave_id, int k) {
+    return P.counters + (size_t)(wave_id & (uint32_t)(kCounterSlots - 1)) * kCounterStride + k;
+}
 RT_D unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1)
         v += __shfl_xor(v, off, 64);
@@ -477,16 +484,17 @@ __global__ void __launch_bounds__(256) k_trace(const KParams P) {
             P.image[pixel] = px;
         }
     }
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     unsigned long long r = wave_sum(cnt.rays);
-    if (lane == 0)
-        atomicAdd(&P.counters[0], r);
+    if (lane == 0 && r != 0ull)
+        atomicAdd(counter_slot(P, wave_id, 0), r);
     if (STATS) {
         unsigned long long b = wave_sum(cnt.box), t = wave_sum(cnt.tri), s = wave_sum(cnt.sph), h = wave_sum(cnt.trih);
-        if (lane == 0) {
-            atomicAdd(&P.counters[1], b);
-            atomicAdd(&P.counters[2], t);
-            atomicAdd(&P.counters[3], s);
-            atomicAdd(&P.counters[4], h);
+        if (lane == 0 && r != 0ull) {
+            atomicAdd(counter_slot(P, wave_id, 1), b);
+            atomicAdd(counter_slot(P, wave_id, 2), t);
+            atomicAdd(counter_slot(P, wave_id, 3), s);
+            atomicAdd(counter_slot(P, wave_id, 4), h);
         }
     }
 }
@@ -891,6 +899,166 @@ struct Path {
     uint32_t key; // RNG key of (pixel, sample)
 };
 
+// Shades one finished closest-hit search: the path either ENDS (its colour goes to colors[sample][pixel]; returns
+// true) or CONTINUES with a new ray in `path` (returns false).  Also records the primary-hit id of the first sample.
+template <bool OLD, bool STATS>
+RT_D bool shade_path(const KParams &P, Path &path, const Best &hit, const uint32_t cidx, Cnt &cnt) {
+    bool ended = false;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t dim = 3u + 4u * (uint32_t)path.depth;
+    const bool first = path.depth == 0;
+    path.depth++;
+    uint32_t prim = kNone;
+    if (!OLD) { // Trace::CastRay(ray, depth, sd::DataStorage&), CPURayTrace/Trace.cpp:58-96
+        if (hit.ref != kNone) {
+            if (STATS)
+                cnt.trih++;
+            const float4 q2 = P.tri_pos[3 * hit.ref + 2];
+            prim = __float_as_uint(q2.y);
+            if (__float_as_uint(q2.z) == 0u) { // LambertianMat; otherwise the same ray is cast again (Trace.cpp:80-82)
+                f3 N = tri_normal(P, hit.ref, hit.u, hit.v);
+                f3 pos = path.o + hit.t * path.d;
+                f3 bias = N * 1e-5f; // Lambertian::Hit, Materials/Lambertian.hpp:35-48
+                float u1 = rng01(path.key, dim + 1u);
+                float u2 = rng01(path.key, dim + 2u);
+                path.d = cosine_dir(N, u1, u2);
+                path.o = pos + bias;
+                path.thr = make_float4(path.thr.x * 0.9f, path.thr.y * 0.6f, path.thr.z * 0.5f, 1.f);
+            }
+            ended = !(path.depth < P.bounce_limit); // loop condition of Trace.cpp:63: colour stays (0,0,0,0)
+        } else {
+            f3 sk = sky_color(path.d);
+            c = make_float4(0.f + path.thr.x * sk.x, 0.f + path.thr.y * sk.y, 0.f + path.thr.z * sk.z, 0.f + 1.0f);
+            ended = true;
+        }
+    } else { // Trace::CastRay(ray, depth, const Scene&), CPURayTrace/Trace.cpp:31-56, products taken front to back
+        const float rr = path.rr;
+        if (hit.ref == kNone) {
+            f3 sk = sky_color(path.d);
+            c = make_float4((path.thr.x * sk.x) * rr, (path.thr.y * sk.y) * rr, (path.thr.z * sk.z) * rr,
+                            (path.thr.w * 1.0f) * rr);
+            ended = true;
+        } else {
+            f3 pos = path.o + hit.t * path.d;
+            f3 N;
+            uint32_t mat;
+            if (hit.ref & kSphereBit) {
+                const uint32_t si = hit.ref & ~kSphereBit;
+                const float4 s0 = P.spheres[2 * si], s1 = P.spheres[2 * si + 1];
+                N = normalize3(pos - mk3(s0.x, s0.y, s0.z));
+                mat = __float_as_uint(s1.x);
+                prim = __float_as_uint(s1.y);
+            } else {
+                if (STATS)
+                    cnt.trih++;
+                const float4 q2 = P.tri_pos[3 * hit.ref + 2];
+                N = tri_normal(P, hit.ref, hit.u, hit.v);
+                prim = __float_as_uint(q2.y);
+                mat = __float_as_uint(q2.z);
+            }
+            const float4 m0 = P.mats[2 * mat], m1 = P.mats[2 * mat + 1];
+            const uint32_t mkind = __float_as_uint(m1.x);
+            const float param = m1.y;
+            path.thr = make_float4((path.thr.x * m0.x) * rr, (path.thr.y * m0.y) * rr, (path.thr.z * m0.z) * rr,
+                                   (path.thr.w * m0.w) * rr);
+            if (mkind == RT_MAT_EMIT) { // LightEmit::getIrradiance, Materials/LightEmit.hpp:11-14
+                c = path.thr;
+                ended = true;
+            } else {
+                f3 no, nd;
+                if (mkind == RT_MAT_DIELECTRIC) { // no reference counterpart: Snell + Schlick
+                    f3 unit = normalize3(path.d);
+                    bool front = dot3(unit, N) < 0.0f;
+                    f3 nn = front ? N : -N;
+                    float ri = front ? (1.0f / param) : param;
+                    float dn = dot3(-unit, nn);
+                    float cosT = (1.0f < dn) ? 1.0f : dn;
+                    float sinT = sqrtf(1.0f - cosT * cosT);
+                    bool cannot = ri * sinT > 1.0f;
+                    float pick = rng01(path.key, dim + 3u);
+                    f3 bias = nn * 1e-4f;
+                    if (cannot || reflectance(cosT, ri) > pick) {
+                        nd = unit - nn * dot3(unit, nn) * 2.f;
+                        no = pos + bias;
+                    } else {
+                        f3 perp = ri * (unit + cosT * nn);
+                        f3 par = nn * -sqrtf(fabsf(1.0f - dot3(perp, perp)));
+                        nd = perp + par;
+                        no = pos - bias;
+                    }
+                } else { // Lambertian (Materials/Lambertian.hpp:16-29) or Metal (Materials/Metal.hpp:15-31)
+                    f3 bias = N * 1e-4f;
+                    float u1 = rng01(path.key, dim + 1u);
+                    float u2 = rng01(path.key, dim + 2u);
+                    f3 rnd = cosine_dir(N, u1, u2);
+                    if (mkind == RT_MAT_METAL) {
+                        f3 refl = path.d - N * dot3(path.d, N) * 2.f;
+                        nd = normalize3(rnd * param + refl * (1 - param));
+                    } else {
+                        nd = rnd;
+                    }
+                    no = pos + bias;
+                }
+                path.o = no;
+                path.d = nd;
+                // entry test of the next CastRay call (Trace.cpp:33-38): roulette, then the depth cap
+                float nrr = 1.0f;
+                if (path.depth > 1)
+                    nrr = rng01(path.key, 3u + 4u * (uint32_t)path.depth) < 0.8f ? 1.0f / 0.8f : 0.0f;
+                if (path.depth > P.bounce_limit || nrr == 0.0f)
+                    ended = true; // that call returns zero
+                path.rr = nrr;
+            }
+        }
+    }
+    if (first && P.primary != nullptr && P.chunk_first + (int)(cidx / P.npix) == P.first_sample)
+        P.primary[cidx % P.npix] = prim;
+    if (ended)
+        P.colors[cidx] = c;
+    return ended;
+}
+
+// Camera ray of work item `item` = (tile ordinal, sample in chunk, pixel in the 8x8 tile); returns false for a pixel
+// outside the image (or when the estimator starts no traversal at all).
+template <bool OLD>
+RT_D bool camera_path(const KParams &P, const uint32_t item, Path &path, uint32_t &cidx) {
+    const uint32_t per_tile = 64u * (uint32_t)P.S;
+    const uint32_t j = item / per_tile;
+    const uint32_t s = (item - j * per_tile) >> 6;
+    const uint32_t in_tile = item & 63u;
+    const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
+    const int x = (int)(tile % (uint32_t)P.tiles_x) * 8 + (int)(in_tile & 7u);
+    const int y = (int)(tile / (uint32_t)P.tiles_x) * 8 + (int)(in_tile >> 3);
+    bool live = item < P.n_items && x < P.W && y < P.H;
+    const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+    const int n = P.chunk_first + (int)s;
+    cidx = s * P.npix + pixel;
+    // CPUImageData::uvAt, Renderer/TraceMethods.hpp:30; Camera::getRayDirction, Camera.hpp:33-47
+    const float u = (float)x / (float)P.W, v = (float)y / (float)P.H;
+    f3 view = normalize3(mk3(u * P.cam_w - P.cam_w / 2, v * P.cam_h - P.cam_h / 2, P.focal));
+    view.x = -view.x;
+    const f3 dir0 = basis_mul(P.bx, P.by, P.bz, view);
+    path.key = pcg(pcg(pcg(P.seed) + pixel) + (uint32_t)n + P.sample_offset);
+    // glm::linearRand(vec3(-s), vec3(s)), Include/Random.hpp:13-16
+    const float js = P.jitter;
+    f3 jit = mk3(rng01(path.key, 0u) * (js - (-js)) + (-js), rng01(path.key, 1u) * (js - (-js)) + (-js),
+                 rng01(path.key, 2u) * (js - (-js)) + (-js));
+    path.o = P.cam_pos;
+    path.d = dir0 + jit;
+    path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
+    path.rr = 1.0f;
+    path.depth = 0;
+    if (!OLD && P.bounce_limit <= 0) { // Trace.cpp:63: no traversal at all, the sample is (0,0,0,0)
+        if (live) {
+            P.colors[cidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (P.primary != nullptr && n == P.first_sample)
+                P.primary[pixel] = kNone;
+        }
+        live = false;
+    }
+    return live;
+}
+
 // Wavefront path kernel: one launch per bounce level.
 //
 // Level 0 generates the camera rays of `S` consecutive samples of every pixel this context owns.  A
@@ -907,7 +1075,25 @@ template <bool OLD, bool STATS, int WALK>
 __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-    const uint32_t n_in = P.level == 0 ? P.n_items : *P.n_in;
+    // Level 0: items are camera rays, batch b = items 64 b .. 64 b + 63.  Deeper levels: the queue is kSubQueues
+    // sub-queues (sub-queue q = the paths appended by batches b with b % 64 == q of the level before); lane q of
+    // every wave reads count q, a wave scan turns the counts into batch ranges, and batch b of this level is looked
+    // up with one ballot.
+    uint32_t sub_count = 0u, sub_end = 0u; // lane q: records in sub-queue q; batches in sub-queues 0..q
+    uint32_t n_batches;
+    if (P.level == 0) {
+        n_batches = (P.n_items + 63u) >> 6;
+    } else {
+        sub_count = P.sub_in[lane * 32u];
+        sub_end = (sub_count + 63u) >> 6;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)sub_end, off, 64);
+            if ((int)lane >= off)
+                sub_end += up;
+        }
+        n_batches = (uint32_t)__builtin_amdgcn_readlane((int)sub_end, 63);
+    }
+    const uint32_t n_in = P.level == 0 ? P.n_items : n_batches * 64u;
     // A level with too few rays to fill the chip is bound by the latency of one walk, which is shortest
     // when every lane walks alone; a level that saturates the chip is bound by throughput.
     const bool use_wave = WALK == WALK_WAVE && n_in >= P.wave_min_rays;
@@ -917,46 +1103,20 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
     // the image is spread over the whole grid.
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (uint64_t base64 = (uint64_t)wave_id * 64u; base64 < n_in; base64 += (uint64_t)n_waves * 64u) {
-        const uint32_t base = (uint32_t)base64;
-        const uint32_t g = base + lane;
+    for (uint32_t batch = wave_id; batch < n_batches; batch += n_waves) {
+        uint32_t g = batch * 64u + lane; // level 0: item number; deeper: record number in the queue
         bool live = g < n_in;
+        if (P.level != 0) {
+            const uint32_t q = (uint32_t)__builtin_popcountll(__ballot(sub_end <= batch));
+            const uint32_t first = q == 0u ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sub_end, (int)q - 1);
+            const uint32_t local = (batch - first) * 64u + lane;
+            live = local < (uint32_t)__builtin_amdgcn_readlane((int)sub_count, (int)q);
+            g = q * P.sub_cap + local;
+        }
         Path path;
         uint32_t cidx = 0;
         if (P.level == 0) {
-            const uint32_t per_tile = 64u * (uint32_t)P.S;
-            const uint32_t j = base / per_tile;
-            const uint32_t s = (base - j * per_tile) >> 6;
-            const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
-            const int x = (int)(tile % (uint32_t)P.tiles_x) * 8 + (int)(lane & 7u);
-            const int y = (int)(tile / (uint32_t)P.tiles_x) * 8 + (int)(lane >> 3);
-            live = live && x < P.W && y < P.H;
-            const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
-            const int n = P.chunk_first + (int)s;
-            cidx = s * P.npix + pixel;
-            // CPUImageData::uvAt, Renderer/TraceMethods.hpp:30; Camera::getRayDirction, Camera.hpp:33-47
-            const float u = (float)x / (float)P.W, v = (float)y / (float)P.H;
-            f3 view = normalize3(mk3(u * P.cam_w - P.cam_w / 2, v * P.cam_h - P.cam_h / 2, P.focal));
-            view.x = -view.x;
-            const f3 dir0 = basis_mul(P.bx, P.by, P.bz, view);
-            path.key = pcg(pcg(pcg(P.seed) + pixel) + (uint32_t)n + P.sample_offset);
-            // glm::linearRand(vec3(-s), vec3(s)), Include/Random.hpp:13-16
-            const float js = P.jitter;
-            f3 jit = mk3(rng01(path.key, 0u) * (js - (-js)) + (-js), rng01(path.key, 1u) * (js - (-js)) + (-js),
-                         rng01(path.key, 2u) * (js - (-js)) + (-js));
-            path.o = P.cam_pos;
-            path.d = dir0 + jit;
-            path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
-            path.rr = 1.0f;
-            path.depth = 0;
-            if (!OLD && P.bounce_limit <= 0) { // Trace.cpp:63: no traversal at all, the sample is (0,0,0,0)
-                if (live) {
-                    P.colors[cidx] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (P.primary != nullptr && n == P.first_sample)
-                        P.primary[pixel] = kNone;
-                }
-                live = false;
-            }
+            live = camera_path<OLD>(P, g, path, cidx);
         } else {
             path.o = path.d = mk3(1.f, 1.f, 1.f);
             path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -1002,119 +1162,8 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
         }
         // ---- shade: the path ends with a colour or continues with a new ray ----
         ended = false;
-        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) {
-            const uint32_t dim = 3u + 4u * (uint32_t)path.depth;
-            const bool first = path.depth == 0;
-            path.depth++;
-            uint32_t prim = kNone;
-            if (!OLD) { // Trace::CastRay(ray, depth, sd::DataStorage&), CPURayTrace/Trace.cpp:58-96
-                if (hit.ref != kNone) {
-                    if (STATS)
-                        cnt.trih++;
-                    const float4 q2 = P.tri_pos[3 * hit.ref + 2];
-                    prim = __float_as_uint(q2.y);
-                    if (__float_as_uint(q2.z) == 0u) { // LambertianMat; otherwise the same ray is cast again (Trace.cpp:80-82)
-                        f3 N = tri_normal(P, hit.ref, hit.u, hit.v);
-                        f3 pos = path.o + hit.t * path.d;
-                        f3 bias = N * 1e-5f; // Lambertian::Hit, Materials/Lambertian.hpp:35-48
-                        float u1 = rng01(path.key, dim + 1u);
-                        float u2 = rng01(path.key, dim + 2u);
-                        path.d = cosine_dir(N, u1, u2);
-                        path.o = pos + bias;
-                        path.thr = make_float4(path.thr.x * 0.9f, path.thr.y * 0.6f, path.thr.z * 0.5f, 1.f);
-                    }
-                    ended = !(path.depth < P.bounce_limit); // loop condition of Trace.cpp:63: colour stays (0,0,0,0)
-                } else {
-                    f3 sk = sky_color(path.d);
-                    c = make_float4(0.f + path.thr.x * sk.x, 0.f + path.thr.y * sk.y, 0.f + path.thr.z * sk.z, 0.f + 1.0f);
-                    ended = true;
-                }
-            } else { // Trace::CastRay(ray, depth, const Scene&), CPURayTrace/Trace.cpp:31-56, products taken front to back
-                const float rr = path.rr;
-                if (hit.ref == kNone) {
-                    f3 sk = sky_color(path.d);
-                    c = make_float4((path.thr.x * sk.x) * rr, (path.thr.y * sk.y) * rr, (path.thr.z * sk.z) * rr,
-                                    (path.thr.w * 1.0f) * rr);
-                    ended = true;
-                } else {
-                    f3 pos = path.o + hit.t * path.d;
-                    f3 N;
-                    uint32_t mat;
-                    if (hit.ref & kSphereBit) {
-                        const uint32_t si = hit.ref & ~kSphereBit;
-                        const float4 s0 = P.spheres[2 * si], s1 = P.spheres[2 * si + 1];
-                        N = normalize3(pos - mk3(s0.x, s0.y, s0.z));
-                        mat = __float_as_uint(s1.x);
-                        prim = __float_as_uint(s1.y);
-                    } else {
-                        if (STATS)
-                            cnt.trih++;
-                        const float4 q2 = P.tri_pos[3 * hit.ref + 2];
-                        N = tri_normal(P, hit.ref, hit.u, hit.v);
-                        prim = __float_as_uint(q2.y);
-                        mat = __float_as_uint(q2.z);
-                    }
-                    const float4 m0 = P.mats[2 * mat], m1 = P.mats[2 * mat + 1];
-                    const uint32_t mkind = __float_as_uint(m1.x);
-                    const float param = m1.y;
-                    path.thr = make_float4((path.thr.x * m0.x) * rr, (path.thr.y * m0.y) * rr, (path.thr.z * m0.z) * rr,
-                                           (path.thr.w * m0.w) * rr);
-                    if (mkind == RT_MAT_EMIT) { // LightEmit::getIrradiance, Materials/LightEmit.hpp:11-14
-                        c = path.thr;
-                        ended = true;
-                    } else {
-                        f3 no, nd;
-                        if (mkind == RT_MAT_DIELECTRIC) { // no reference counterpart: Snell + Schlick
-                            f3 unit = normalize3(path.d);
-                            bool front = dot3(unit, N) < 0.0f;
-                            f3 nn = front ? N : -N;
-                            float ri = front ? (1.0f / param) : param;
-                            float dn = dot3(-unit, nn);
-                            float cosT = (1.0f < dn) ? 1.0f : dn;
-                            float sinT = sqrtf(1.0f - cosT * cosT);
-                            bool cannot = ri * sinT > 1.0f;
-                            float pick = rng01(path.key, dim + 3u);
-                            f3 bias = nn * 1e-4f;
-                            if (cannot || reflectance(cosT, ri) > pick) {
-                                nd = unit - nn * dot3(unit, nn) * 2.f;
-                                no = pos + bias;
-                            } else {
-                                f3 perp = ri * (unit + cosT * nn);
-                                f3 par = nn * -sqrtf(fabsf(1.0f - dot3(perp, perp)));
-                                nd = perp + par;
-                                no = pos - bias;
-                            }
-                        } else { // Lambertian (Materials/Lambertian.hpp:16-29) or Metal (Materials/Metal.hpp:15-31)
-                            f3 bias = N * 1e-4f;
-                            float u1 = rng01(path.key, dim + 1u);
-                            float u2 = rng01(path.key, dim + 2u);
-                            f3 rnd = cosine_dir(N, u1, u2);
-                            if (mkind == RT_MAT_METAL) {
-                                f3 refl = path.d - N * dot3(path.d, N) * 2.f;
-                                nd = normalize3(rnd * param + refl * (1 - param));
-                            } else {
-                                nd = rnd;
-                            }
-                            no = pos + bias;
-                        }
-                        path.o = no;
-                        path.d = nd;
-                        // entry test of the next CastRay call (Trace.cpp:33-38): roulette, then the depth cap
-                        float nrr = 1.0f;
-                        if (path.depth > 1)
-                            nrr = rng01(path.key, 3u + 4u * (uint32_t)path.depth) < 0.8f ? 1.0f / 0.8f : 0.0f;
-                        if (path.depth > P.bounce_limit || nrr == 0.0f)
-                            ended = true; // that call returns zero
-                        path.rr = nrr;
-                    }
-                }
-            }
-            if (first && P.primary != nullptr && P.chunk_first + (int)(cidx / P.npix) == P.first_sample)
-                P.primary[cidx % P.npix] = prim;
-            if (ended)
-                P.colors[cidx] = c;
-        }
+        if (live)
+            ended = shade_path<OLD, STATS>(P, path, hit, cidx, cnt);
         if (P.tail == 0)
             break;
         live = live && !ended;
@@ -1125,12 +1174,13 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
         const bool cont = live && !ended;
         const unsigned long long cmask = __ballot(cont);
         if (cmask != 0ull) {
+            const uint32_t q = batch & (uint32_t)(kSubQueues - 1);
             unsigned int obase = 0;
             if (lane == 0)
-                obase = atomicAdd(P.n_out, (unsigned int)__builtin_popcountll(cmask));
+                obase = atomicAdd(P.sub_out + q * 32u, (unsigned int)__builtin_popcountll(cmask));
             obase = __builtin_amdgcn_readfirstlane(obase);
             if (cont) {
-                const size_t slot = (size_t)obase + (size_t)__builtin_popcountll(cmask & ((1ull << lane) - 1ull));
+                const size_t slot = (size_t)q * P.sub_cap + (size_t)obase + (size_t)__builtin_popcountll(cmask & ((1ull << lane) - 1ull));
                 P.q_out[4 * slot] = make_float4(path.o.x, path.o.y, path.o.z, path.d.x);
                 P.q_out[4 * slot + 1] = make_float4(path.d.y, path.d.z, path.thr.x, path.thr.y);
                 P.q_out[4 * slot + 2] = make_float4(path.thr.z, path.thr.w, path.rr, __uint_as_float(path.key));
@@ -1140,24 +1190,24 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
     }
     // Counters: one atomic per wave that has something to add.  (Thousands of same-address atomics are
     // serialised by the memory system; a launch whose level is empty must not pay for them.)
-    if (n_in == 0u)
+    if (n_batches == 0u)
         return;
     unsigned long long r = wave_sum(cnt.rays);
     if (lane == 0 && r != 0ull)
-        atomicAdd(&P.counters[0], r);
+        atomicAdd(counter_slot(P, wave_id, 0), r);
     if (STATS) {
         unsigned long long b = wave_sum(cnt.box), t = wave_sum(cnt.tri), s = wave_sum(cnt.sph), h = wave_sum(cnt.trih);
         if (lane == 0 && r != 0ull) {
-            atomicAdd(&P.counters[1], b);
-            atomicAdd(&P.counters[2], t);
-            atomicAdd(&P.counters[3], s);
-            atomicAdd(&P.counters[4], h);
+            atomicAdd(counter_slot(P, wave_id, 1), b);
+            atomicAdd(counter_slot(P, wave_id, 2), t);
+            atomicAdd(counter_slot(P, wave_id, 3), s);
+            atomicAdd(counter_slot(P, wave_id, 4), h);
         }
     }
     if (WALK == WALK_FAST) {
         unsigned long long rp = wave_sum(cnt.replay);
         if (lane == 0 && rp != 0ull)
-            atomicAdd(&P.counters[5], rp);
+            atomicAdd(counter_slot(P, wave_id, 5), rp);
     }
 }
 
@@ -1341,7 +1391,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     P.focal = c.focal_length;
 
     RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, 64, ctx->stream));
-    RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 64, ctx->stream));
+    RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, kCounterSlots * kCounterStride * sizeof(unsigned long long), ctx->stream));
     const bool old = o.estimator == RT_EST_OLD_RECURSIVE;
     const bool st = o.collect_stats != 0;
     int trav = o.traversal;
@@ -1389,7 +1439,10 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         S = (int)(kMaxItems / items_per_sample);
     if (S < 1)
         S = 1;
-    const size_t need_colors = (size_t)S * npix, need_q = (size_t)S * items_per_sample;
+    // queue capacity: sub-queue q of a level receives the continuing paths of the batches b with b % 64 == q of the
+    // level before, at most 64 paths each, and no level has more batches than level 0 has plus one partial batch per
+    // sub-queue: (n_batches / 64 + 2) * 64 records per sub-queue always suffice
+    const size_t need_colors = (size_t)S * npix, need_q = (size_t)S * items_per_sample + (size_t)kSubQueues * 128;
     if (need_colors > ctx->colors_cap || need_q > ctx->q_cap) {
         RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_colors) (void)hipFree(ctx->d_colors);
@@ -1411,18 +1464,18 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         const int s_now = count - done < S ? count - done : S;
         if (s_now <= 0)
             break;
-        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_levels, 0, 2 * kMaxLevels * sizeof(unsigned int), ctx->stream));
+        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_levels, 0, (size_t)(levels + 1) * kSubQueues * 32 * sizeof(unsigned int), ctx->stream));
         P.S = s_now;
         P.chunk_first = first + done;
         P.n_items = (uint32_t)((size_t)s_now * items_per_sample);
+        P.sub_cap = (((P.n_items + 63u) / 64u) / (uint32_t)kSubQueues + 2u) * 64u;
         for (int level = 0; level < levels; level++) {
             P.level = level;
             P.tail = (level >= kTailLevel || level == levels - 1) ? 1 : 0;
             P.q_in = ctx->d_q[level & 1];
             P.q_out = ctx->d_q[(level + 1) & 1];
-            P.cursor = ctx->d_levels + level;
-            P.n_in = ctx->d_levels + kMaxLevels + level;
-            P.n_out = ctx->d_levels + kMaxLevels + level + 1;
+            P.sub_in = ctx->d_levels + (size_t)level * kSubQueues * 32;
+            P.sub_out = ctx->d_levels + (size_t)(level + 1) * kSubQueues * 32;
             uint32_t blocks = full_grid;
             if (level == 0 && blocks > (P.n_items / 64 + 3) / 4)
                 blocks = (P.n_items / 64 + 3) / 4;
@@ -1462,8 +1515,13 @@ int sync_and_stats(rt_ctx *ctx, rt_stats *stats) {
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         if (ctx->pending > 0) {
-            unsigned long long h[6];
-            RT_HIP_CHECK(ctx, hipMemcpy(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+            unsigned long long slots[kCounterSlots * kCounterStride], h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            RT_HIP_CHECK(ctx, hipMemcpy(slots, ctx->d_counters, sizeof(slots), hipMemcpyDeviceToHost));
+            for (int sl = 0; sl < kCounterSlots; sl++)
+                for (int k = 0; k < 8; k++) {
+                    const unsigned long long v = slots[sl * kCounterStride + k];
+                    h[k] += v;
+                }
             stats->rays = h[0];
             stats->box_tests = h[1];
             stats->tri_tests = h[2];
@@ -1510,8 +1568,8 @@ int rt_create(rt_ctx **out, int device) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
     ctx->own_stream = true;
     if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) return bail("hipMalloc");
-    if (hipMalloc((void **)&ctx->d_counters, 64) != hipSuccess) return bail("hipMalloc");
-    if (hipMalloc((void **)&ctx->d_levels, 2 * kMaxLevels * sizeof(unsigned int)) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void **)&ctx->d_counters, kCounterSlots * kCounterStride * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void **)&ctx->d_levels, (size_t)(kMaxLevels + 1) * kSubQueues * 32 * sizeof(unsigned int)) != hipSuccess) return bail("hipMalloc");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail("hipGetDeviceProperties");
     ctx->num_cus = prop.multiProcessorCount;
