@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=0, help="cpu_baseline sample: samples per pixel (0 = sized from a probe)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="cpu_baseline sample: target seconds per timed render")
     args = ap.parse_args()
+    if os.environ.get("RT_BENCH_WATCHDOG"):  # dump every thread's stack if the run is still going after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
 
     import numpy as np
     import torch
@@ -100,6 +103,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    def note(msg):  # progress on stderr (a multi-minute run must not look hung)
+        print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
     wl = WL.make_workload(args.workload)
     spp = args.spp or wl.spp
     W, H = wl.width, wl.height
@@ -111,11 +117,16 @@ def main():
 
     def options(stats, traversal=R.TRAV_FAST):
         tr.set_options(bounce_limit=wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
-                       collect_stats=stats, sample_offset=P.sample_offset(rank, spp), traversal=traversal)
+                       collect_stats=stats, sample_offset=P.sample_offset(rank, spp * max(args.steps, args.warmup)),
+                       traversal=traversal)
 
-    def step():
-        tr.trace_device(W, H, 1, spp, img.data_ptr())
-        P.combine_sample_split(img, dst=0)  # N > 1: one RCCL reduce(SUM) of the per-rank means, / world on rank 0
+    # One render = `n` steps of `spp` samples accumulated into the running mean on the device (the reference's
+    # progressive sampleCount protocol, Renderer/TracerImpl.cpp:9-12), then -- N > 1 -- ONE RCCL reduce(SUM) of the
+    # per-rank means, / world on rank 0.  Rank r draws the sample indices r * n * spp + 1 ... (r + 1) * n * spp.
+    def render(n):
+        for i in range(n):
+            tr.trace_device(W, H, 1 + i * spp, spp, img.data_ptr())
+        P.combine_sample_split(img, dst=0)
 
     # work of one trace call: counted once, untimed, by the counting variant of the same kernel
     options(True)
@@ -131,24 +142,25 @@ def main():
         ref_counts = tr.sync()
         assert ref_counts.rays == counts.rays and ref_counts.tri_hits == counts.tri_hits
     options(False)
+    note(f"scene uploaded, work counted ({counts.rays} rays per step)")
 
-    for _ in range(args.warmup):
-        step()
+    render(args.warmup)
     tr.sync()
+    note("warm-up done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    render(args.steps)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    note(f"{args.steps} timed steps in {elapsed * 1e3:.2f} ms")
     st = tr.sync()
-    assert st.launches == args.steps and st.rays == counts.rays
+    assert st.launches == args.steps  # st.rays: closest-hit searches of all the timed steps of this rank
 
-    total = torch.tensor([elapsed, float(st.rays) * args.steps], dtype=torch.float64, device=dev)
+    total = torch.tensor([elapsed, float(st.rays)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = total.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -185,10 +197,10 @@ def main():
             "data": "Stanford Dragon mesh bundled with the reference (data/models), no external data"
                     if wl.estimator == R.EST_SD_LOOP else "synthetic",
             "config": {"workload": wl.name, "width": W, "height": H, "spp_per_step_per_gpu": spp,
-                       "bounce_limit": wl.bounce_limit, "rays_per_step_per_gpu": int(st.rays),
+                       "bounce_limit": wl.bounce_limit, "rays_per_step_per_gpu": int(st.rays // args.steps),
                        "traversal": "fast walk (own hierarchy over the reference's leaf boxes; hits bit-identical "
                                     "to the reference-order walk)",
-                       "parallelism": "scene replicated, sample-index range per GPU, one RCCL reduce per step"
+                       "parallelism": "scene replicated, sample-index range per GPU, steps accumulate on the device, one RCCL reduce of the W*H*4 float mean at the end of the render"
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

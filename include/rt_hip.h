@@ -133,7 +133,8 @@ typedef struct rt_options {
 } rt_options;
 
 typedef struct rt_stats {
-    uint64_t rays;      /* closest-hit traversals started, primary + bounces */
+    uint64_t rays;      /* closest-hit traversals started, primary + bounces; every counter runs from the previous
+                           rt_trace / rt_sync of the context to this one */
     uint64_t box_tests; /* filled when collect_stats != 0 */
     uint64_t tri_tests;
     uint64_t sph_tests;

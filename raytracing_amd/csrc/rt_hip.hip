@@ -1391,7 +1391,6 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     P.focal = c.focal_length;
 
     RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, 64, ctx->stream));
-    RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, kCounterSlots * kCounterStride * sizeof(unsigned long long), ctx->stream));
     const bool old = o.estimator == RT_EST_OLD_RECURSIVE;
     const bool st = o.collect_stats != 0;
     int trav = o.traversal;
@@ -1538,6 +1537,8 @@ int sync_and_stats(rt_ctx *ctx, rt_stats *stats) {
             stats->launches = (uint32_t)ctx->pending;
         }
     }
+    if (ctx->pending > 0) // counters run from one sync to the next
+        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, kCounterSlots * kCounterStride * sizeof(unsigned long long), ctx->stream));
     ctx->pending = 0;
     return RT_OK;
 }
@@ -1569,6 +1570,7 @@ int rt_create(rt_ctx **out, int device) {
     ctx->own_stream = true;
     if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) return bail("hipMalloc");
     if (hipMalloc((void **)&ctx->d_counters, kCounterSlots * kCounterStride * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc");
+    if (hipMemset(ctx->d_counters, 0, kCounterSlots * kCounterStride * sizeof(unsigned long long)) != hipSuccess) return bail("hipMemset");
     if (hipMalloc((void **)&ctx->d_levels, (size_t)(kMaxLevels + 1) * kSubQueues * 32 * sizeof(unsigned int)) != hipSuccess) return bail("hipMalloc");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail("hipGetDeviceProperties");

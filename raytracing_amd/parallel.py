@@ -48,11 +48,23 @@ def tile_owner(x, y, width, world):
     return ((y // 8) * tiles_x + (x // 8)) % world
 
 
+def _reduce_sum(image, dst):
+    """reduce(SUM) onto rank `dst`.  RCCL reduces device tensors in place over xGMI.  gloo (used only to rehearse
+    the multi-rank path where RCCL cannot run, e.g. several ranks sharing one GPU) is given a host copy: its
+    handling of device tensors proved unreliable here (a second reduce of the same CUDA tensor never returned)."""
+    if image.is_cuda and dist.get_backend() == "gloo":
+        host = image.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+        image.copy_(host)
+    else:
+        dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
+
+
 def combine_tile_split(image, dst=0):
     """image: this rank's (H, W, 4) float32 tensor, zero outside its tiles.  After the call rank `dst`
     holds the assembled image."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
+        _reduce_sum(image, dst)
     return image
 
 
@@ -61,7 +73,7 @@ def combine_sample_split(image, dst=0):
     ranks' samples."""
     if dist.is_initialized() and dist.get_world_size() > 1:
         world = dist.get_world_size()
-        dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
+        _reduce_sum(image, dst)
         if dist.get_rank() == dst:
             image /= world
     return image
