@@ -189,6 +189,29 @@ int rt_set_stream(rt_ctx *ctx, void *hip_stream);
 /* Waits for the context's stream and reports the counters and kernel time of the last trace. */
 int rt_sync(rt_ctx *ctx, rt_stats *stats);
 
+/* Host-only view of what rt_upload_scene lays out for the device, for inspection and tests; no HIP call is made.
+ * It is this build's counterpart of the reference's own flattening for its GL tracer (LoadSdSceneGPU::load,
+ * Renderer/LoadMethods.cpp:16-51, via sd::ConvertNodeToFlatStorage, CPURayTrace/SimplifiedData.cpp:162-185).
+ * Node records are 8 floats: pMin.xyz, pMax.xyz, skip (uint32 bits: byte offset of the first record after the
+ * subtree), word (uint32 bits).  Fast tree: word = byte offset of the right child for an interior node (low three
+ * bits 0), (slot << 3) | kind for a triangle / sphere leaf, (reference position << 3) | RT_NODE_MESH for a mesh
+ * leaf, whose own tree follows inline.  Reference-order tree: word = (slot << 3) | kind, and one terminator record
+ * follows the last node.  tri_pos: 12 floats per slot = p0, e1, e2, triangle index, material, reference position
+ * of the leaf (last three as uint32 bits), in fast-tree leaf order.  spheres: 8 floats per slot = centre, radius,
+ * material, primitive id, dielectric flag, reference position. */
+typedef struct rt_layout_view {
+    uint32_t n_fast_nodes, n_ref_nodes, n_tri_slots, n_sphere_slots;
+    const float *fast_nodes;
+    const float *ref_nodes;
+    const float *tri_pos;
+    const float *spheres;
+    void *owner_;
+} rt_layout_view;
+int rt_layout_scene(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt_tri *tris, uint32_t n_tris,
+                    const rt_sphere *spheres, uint32_t n_spheres, const rt_material *mats, uint32_t n_mats, int order,
+                    rt_layout_view *out);
+void rt_layout_free(rt_layout_view *view);
+
 /* Library self-description: "rt_hip <version> gfx950". */
 const char *rt_version(void);
 

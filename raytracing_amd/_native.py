@@ -48,11 +48,18 @@ class StatsC(C.Structure):  # rt_stats
                 ("launches", C.c_uint32)]
 
 
+class LayoutViewC(C.Structure):  # rt_layout_view
+    _fields_ = [("n_fast_nodes", C.c_uint32), ("n_ref_nodes", C.c_uint32), ("n_tri_slots", C.c_uint32),
+                ("n_sphere_slots", C.c_uint32), ("fast_nodes", C.POINTER(C.c_float)), ("ref_nodes", C.POINTER(C.c_float)),
+                ("tri_pos", C.POINTER(C.c_float)), ("spheres", C.POINTER(C.c_float)), ("owner_", C.c_void_p)]
+
+
 assert C.sizeof(Node) == 36 and C.sizeof(Tri) == 100 and C.sizeof(Sphere) == 24 and C.sizeof(Material) == 24
 
 # every symbol include/rt_hip.h declares
 HIP_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_set_options",
-               "rt_reset", "rt_trace", "rt_trace_device", "rt_set_stream", "rt_sync", "rt_version"]
+               "rt_reset", "rt_trace", "rt_trace_device", "rt_set_stream", "rt_sync", "rt_version", "rt_layout_scene",
+               "rt_layout_free"]
 
 _hip = None
 _host = None
@@ -81,6 +88,10 @@ def hip():
         L.rt_set_stream.argtypes = [vp, vp]
         L.rt_sync.argtypes = [vp, C.POINTER(StatsC)]
         L.rt_version.restype = C.c_char_p
+        L.rt_layout_scene.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, C.c_int,
+                                      C.POINTER(LayoutViewC)]
+        L.rt_layout_free.argtypes = [C.POINTER(LayoutViewC)]
+        L.rt_layout_free.restype = None
         _hip = L
     return _hip
 

@@ -165,3 +165,26 @@ class OldScene:
     def publish(self):
         if N.host().rth_old_publish(self._h) != 0:
             raise RuntimeError(_err())
+
+
+def device_layout(scene):
+    """What rt_upload_scene lays out for the device, as numpy arrays (host-only; rt_layout_scene): a dict with
+    `fast` and `ref` node records (n, 8) float32, `tri_pos` (slots, 12) and `spheres` (slots, 8)."""
+    nodes, tris, sph, mats = scene.nodes(), scene.tris(), scene.spheres(), scene.materials()
+
+    def ptr(a):
+        return a.ctypes.data if len(a) else None
+    v = N.LayoutViewC()
+    rc = N.hip().rt_layout_scene(ptr(nodes), len(nodes), scene.root, ptr(tris), len(tris), ptr(sph), len(sph), ptr(mats),
+                                 len(mats), scene.order, C.byref(v))
+    if rc != 0:
+        raise RuntimeError(f"rt_layout_scene failed: {rc}")
+
+    def grab(p, rows, cols):
+        if rows == 0:
+            return np.zeros((0, cols), dtype=np.float32)
+        return np.ctypeslib.as_array(p, shape=(rows, cols)).copy()
+    out = {"fast": grab(v.fast_nodes, v.n_fast_nodes, 8), "ref": grab(v.ref_nodes, v.n_ref_nodes + 1, 8),
+           "tri_pos": grab(v.tri_pos, v.n_tri_slots, 12), "spheres": grab(v.spheres, v.n_sphere_slots, 8)}
+    N.hip().rt_layout_free(C.byref(v))
+    return out

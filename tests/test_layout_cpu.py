@@ -1,0 +1,173 @@
+"""Host-only checks of what rt_upload_scene lays out for the device (rt_layout_scene; no GPU needed).
+
+The fast walk's exactness argument rests on three properties of the fast tree, checked here on real scenes:
+every leaf of the reference tree appears exactly once with its box kept bit for bit; every interior box is
+the exact union of the boxes below it (so it contains them); and the pre-order links (skip, right child) are
+consistent, so that "descend = next record, prune = skip" visits every leaf whose ancestors' boxes pass.
+The reference-order array must be the reference's own tree in its own visiting order.
+"""
+import numpy as np
+
+from helpers import R, WL, objparse
+
+KIND_INTERNAL, KIND_TRI, KIND_MESH, KIND_SPHERE = 0, 1, 2, 4
+
+
+def u32(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def b1(x):
+    """uint32 bit pattern of one float32 as a Python int."""
+    return int(np.asarray(x, dtype=np.float32).reshape(1).view(np.uint32)[0])
+
+
+def reference_order(scene):
+    """Positions of the scene's nodes in the reference's visiting order (right child first for the flat scene,
+    SimplifiedData.cpp:458-459; left first for the pointer scene, BVH.hpp:143-144)."""
+    nodes = scene.nodes()
+    order, stack = [], [scene.root]
+    while stack:
+        ni = stack.pop()
+        order.append(ni)
+        f = nodes["flags"][ni]
+        if f == KIND_INTERNAL:
+            kids = (nodes["left"][ni], nodes["right"][ni])
+            stack.extend(kids if scene.order == 0 else kids[::-1])
+        elif f == KIND_MESH:
+            stack.append(nodes["left"][ni])
+    return order
+
+
+def check_fast_tree(fast, lo, hi, leaves_seen):
+    """Recursively checks the pre-order subtree whose root is record `lo`; returns (bmin, bmax, end)."""
+    skip = b1(fast[lo, 6]) // 32
+    word = b1(fast[lo, 7])
+    bmin, bmax = fast[lo, 0:3], fast[lo, 3:6]
+    assert lo < skip <= hi
+    kind = word & 7
+    if kind == KIND_INTERNAL:
+        right = word // 32
+        assert word % 32 == 0 and lo + 1 < right < skip
+        lmin, lmax, lend = check_fast_tree(fast, lo + 1, right, leaves_seen)
+        assert lend == right
+        rmin, rmax, rend = check_fast_tree(fast, right, skip, leaves_seen)
+        assert rend == skip
+        # exact union: bit-equal to the float min / max of the children
+        assert np.array_equal(u32(bmin), u32(np.minimum(lmin, rmin)))
+        assert np.array_equal(u32(bmax), u32(np.maximum(lmax, rmax)))
+    elif kind == KIND_MESH:
+        leaves_seen.append(("mesh", word >> 3, bmin.copy(), bmax.copy()))
+        if skip > lo + 1:  # the mesh's own tree follows inline; its boxes need not lie inside the mesh's scene-level box
+            _, _, iend = check_fast_tree(fast, lo + 1, skip, leaves_seen)
+            assert iend == skip
+    else:
+        assert skip == lo + 1
+        leaves_seen.append(("tri" if kind == KIND_TRI else "sph", word >> 3, bmin.copy(), bmax.copy()))
+    return bmin, bmax, skip
+
+
+def check_scene(scene):
+    lay = R.device_layout(scene)
+    nodes = scene.nodes()
+    order = reference_order(scene)
+    ref, fast = lay["ref"], lay["fast"]
+    # ---- reference-order array: the reference's own boxes in its own visiting order, terminator at the end
+    assert len(ref) == len(order) + 1
+    for p in (0, 1, len(order) // 2, len(order) - 1):
+        nd = nodes[order[p]]
+        assert np.array_equal(u32(ref[p, 0:3]), u32(nd["pmin"])) and np.array_equal(u32(ref[p, 3:6]), u32(nd["pmax"]))
+    assert np.array_equal(u32(ref[:-1, 0:3]), u32(nodes["pmin"][order])) and np.array_equal(u32(ref[:-1, 3:6]), u32(nodes["pmax"][order]))
+    assert b1(ref[-1, 7]) == 0xFFFFFFFF
+    ref_kind = u32(ref[:-1, 7]) & 7
+    assert np.array_equal(ref_kind, nodes["flags"][order].astype(np.uint32))
+    skips = u32(ref[:-1, 6]) // 32
+    assert skips[0] == len(order) and np.all(skips > np.arange(len(order))) and np.all(skips <= len(order))
+    # ---- fast tree
+    seen = []
+    _, _, end = check_fast_tree(fast, 0, len(fast), seen)
+    assert end == len(fast)
+    pos_of = {ni: p for p, ni in enumerate(order)}
+    leaf_nodes = [ni for ni in order if nodes["flags"][ni] != KIND_INTERNAL]
+    assert len(seen) == len(leaf_nodes)
+    tri_pos, sph = lay["tri_pos"], lay["spheres"]
+    got_positions = []
+    for kind, ref_or_slot, bmin, bmax in seen:
+        if kind == "mesh":
+            p = ref_or_slot
+        elif kind == "tri":
+            p = b1(tri_pos[ref_or_slot, 11])
+            ni = order[p]
+            assert b1(tri_pos[ref_or_slot, 9]) == nodes["left"][ni]  # the triangle this leaf holds
+        else:
+            p = b1(sph[ref_or_slot, 7])
+        got_positions.append(p)
+        nd = nodes[order[p]]
+        # the leaf keeps the reference's own leaf box, bit for bit
+        assert np.array_equal(u32(bmin), u32(nd["pmin"])) and np.array_equal(u32(bmax), u32(nd["pmax"]))
+    assert sorted(got_positions) == sorted(pos_of[ni] for ni in leaf_nodes)  # every reference leaf exactly once
+    # triangle records: slot order = fast-tree leaf order, edges = the test's own subtractions
+    tris = scene.tris()
+    tri_slots = [s for k, s, _, _ in seen if k == "tri"]
+    assert tri_slots == list(range(len(tri_slots)))
+    for s in (0, len(tri_slots) // 3, len(tri_slots) - 1) if tri_slots else ():
+        t = tris[b1(tri_pos[s, 9])]
+        assert np.array_equal(u32(tri_pos[s, 0:3]), u32(t["pos"][0]))
+        assert np.array_equal(u32(tri_pos[s, 3:6]), u32(t["pos"][1] - t["pos"][0]))
+        assert np.array_equal(u32(tri_pos[s, 6:9]), u32(t["pos"][2] - t["pos"][0]))
+    return lay, seen
+
+
+def test_flat_scene_layout_dragon2426():
+    lay, seen = check_scene(R.SdScene().load_obj(WL.DRAGON_2426).finalize())
+    assert len(seen) == 2426 and len(lay["fast"]) == 2 * 2426 - 1
+
+
+def test_flat_scene_layout_quirk_tree_dragon18520():
+    """The reference tree of this mesh has every big box stretched to z = 0 (FLT_MIN as initial pMax,
+    SimplifiedData.hpp:64-69); the fast tree above the same leaves does not."""
+    sc = R.SdScene().load_obj(WL.DRAGON_18520).finalize()
+    lay, seen = check_scene(sc)
+    nodes = sc.nodes()
+    assert nodes["pmax"][sc.root][2] > 0.0 and nodes["pmax"][sc.root][2] < 1e-30   # the quirk itself
+    assert lay["fast"][0, 5] < -0.8                                               # exact union: the dragon's own extent
+    # surface-area measure of the expected slab tests per ray: two orders of magnitude apart
+    def cost(rec):
+        e = np.maximum(rec[:, 3:6] - rec[:, 0:3], 0)
+        a = e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 2] * e[:, 0]
+        return a.sum() / a.max()
+    assert cost(lay["ref"][:-1]) > 50 * cost(lay["fast"])
+
+
+def test_multi_mesh_flat_scene_and_field():
+    tris, _ = objparse.load_obj(WL.CYLINDER)
+    grid = WL.dragon_grid_tris(tris, 3)
+    check_scene(R.SdScene().add_model(grid).finalize())
+    t2 = tris.copy().reshape(-1, 3, 8)
+    t2[:, :, 0] += 3.0
+    check_scene(R.SdScene().add_model(tris).add_model(t2.reshape(-1, 24)).finalize())
+
+
+def test_pointer_scene_layout_spheres_and_meshes():
+    tris, _ = objparse.load_obj(WL.CYLINDER)
+    sc = WL.build_old_scene(WL.small_sphere_scene())
+    sc.add_mesh(tris, R.MAT_LAMBERTIAN, (0.8, 0.3, 0.3, 1.0), 0.0)
+    t2 = tris.copy().reshape(-1, 3, 8)
+    t2[:, :, 2] -= 4.0
+    sc.add_mesh(t2.reshape(-1, 24), R.MAT_METAL, (0.8, 0.8, 0.9, 1.0), 0.1)
+    sc.build()
+    lay, seen = check_scene(sc)
+    kinds = [k for k, _, _, _ in seen]
+    assert kinds.count("sph") == 5 and kinds.count("mesh") == 2 and kinds.count("tri") == 2 * len(tris)
+    check_scene(WL.build_old_scene(WL.rtiow_spheres()).build())
+
+
+def test_layout_rejects_bad_trees():
+    sc = R.SdScene().load_obj(WL.CYLINDER).finalize()
+    nodes = sc.nodes().copy()
+    nodes["left"][sc.root] = sc.root  # a cycle
+    v = R._native.LayoutViewC()
+    import ctypes as C
+    rc = R._native.hip().rt_layout_scene(nodes.ctypes.data, len(nodes), sc.root, sc.tris().ctypes.data, len(sc.tris()),
+                                         None, 0, None, 0, 0, C.byref(v))
+    assert rc == -5
