@@ -97,6 +97,7 @@ struct KParams {
     float4 *q_out;              // path records of the next level
     float4 *colors;             // colors[sample in chunk][pixel]
     const unsigned int *sub_in; // levels > 0: record counts of this level's sub-queues (one per 128 bytes)
+    unsigned int *sub_cursor;   // levels > 0: batch cursors of this level's sub-queues (one per 128 bytes)
     unsigned int *sub_out;      // append counters of the next level's sub-queues
     uint32_t sub_cap;           // records a sub-queue can hold; sub-queue q starts at record q * sub_cap
     uint32_t n_items;           // level 0: n_my_tiles * 64 * S
@@ -1103,15 +1104,33 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
     // the image is spread over the whole grid.
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (uint32_t batch = wave_id; batch < n_batches; batch += n_waves) {
-        uint32_t g = batch * 64u + lane; // level 0: item number; deeper: record number in the queue
-        bool live = g < n_in;
-        if (P.level != 0) {
-            const uint32_t q = (uint32_t)__builtin_popcountll(__ballot(sub_end <= batch));
-            const uint32_t first = q == 0u ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sub_end, (int)q - 1);
-            const uint32_t local = (batch - first) * 64u + lane;
-            live = local < (uint32_t)__builtin_amdgcn_readlane((int)sub_count, (int)q);
-            g = q * P.sub_cap + local;
+    // Level 0: batch b goes to wave b % n_waves (static; the work per batch is even enough and a shared cursor would
+    // be half a million same-address atomics).  Deeper levels: the waves with wave_id % 64 == q share sub-queue q and
+    // draw its batches from that sub-queue's own cursor, so a wave that met long walks simply draws fewer batches.
+    const uint32_t my_q = wave_id & (uint32_t)(kSubQueues - 1);
+    const uint32_t my_count = P.level == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sub_count, (int)my_q);
+    const uint32_t my_batches = (my_count + 63u) >> 6;
+    for (uint32_t turn = 0;; turn++) {
+        uint32_t g, out_q; // g: item number (level 0) or record number in the queue; out_q: sub-queue continuing paths go to
+        bool live;
+        if (P.level == 0) {
+            const uint32_t batch = wave_id + turn * n_waves;
+            if (batch >= n_batches)
+                break;
+            g = batch * 64u + lane;
+            live = g < n_in;
+            out_q = batch & (uint32_t)(kSubQueues - 1);
+        } else {
+            unsigned int b = 0;
+            if (lane == 0)
+                b = atomicAdd(P.sub_cursor + my_q * 32u, 1u);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b >= my_batches)
+                break;
+            const uint32_t local = b * 64u + lane;
+            live = local < my_count;
+            g = my_q * P.sub_cap + local;
+            out_q = (my_q + b) & (uint32_t)(kSubQueues - 1);
         }
         Path path;
         uint32_t cidx = 0;
@@ -1174,7 +1193,7 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
         const bool cont = live && !ended;
         const unsigned long long cmask = __ballot(cont);
         if (cmask != 0ull) {
-            const uint32_t q = batch & (uint32_t)(kSubQueues - 1);
+            const uint32_t q = out_q;
             unsigned int obase = 0;
             if (lane == 0)
                 obase = atomicAdd(P.sub_out + q * 32u, (unsigned int)__builtin_popcountll(cmask));
@@ -1438,10 +1457,10 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         S = (int)(kMaxItems / items_per_sample);
     if (S < 1)
         S = 1;
-    // queue capacity: sub-queue q of a level receives the continuing paths of the batches b with b % 64 == q of the
-    // level before, at most 64 paths each, and no level has more batches than level 0 has plus one partial batch per
-    // sub-queue: (n_batches / 64 + 2) * 64 records per sub-queue always suffice
-    const size_t need_colors = (size_t)S * npix, need_q = (size_t)S * items_per_sample + (size_t)kSubQueues * 128;
+    // queue capacity: a sub-queue of the next level receives the continuing paths (at most 64) of every 64th batch of
+    // level 0, or of every 64th batch of each of this level's 64 sub-queues; no level has more batches than level 0
+    // has plus one partial batch per sub-queue, so (n_batches / 64 + 66) * 64 records per sub-queue always suffice
+    const size_t need_colors = (size_t)S * npix, need_q = (size_t)S * items_per_sample + (size_t)kSubQueues * 66 * 64;
     if (need_colors > ctx->colors_cap || need_q > ctx->q_cap) {
         RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_colors) (void)hipFree(ctx->d_colors);
@@ -1467,13 +1486,14 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         P.S = s_now;
         P.chunk_first = first + done;
         P.n_items = (uint32_t)((size_t)s_now * items_per_sample);
-        P.sub_cap = (((P.n_items + 63u) / 64u) / (uint32_t)kSubQueues + 2u) * 64u;
+        P.sub_cap = (((P.n_items + 63u) / 64u) / (uint32_t)kSubQueues + 66u) * 64u;
         for (int level = 0; level < levels; level++) {
             P.level = level;
             P.tail = (level >= kTailLevel || level == levels - 1) ? 1 : 0;
             P.q_in = ctx->d_q[level & 1];
             P.q_out = ctx->d_q[(level + 1) & 1];
             P.sub_in = ctx->d_levels + (size_t)level * kSubQueues * 32;
+            P.sub_cursor = ctx->d_levels + (size_t)level * kSubQueues * 32 + 1;
             P.sub_out = ctx->d_levels + (size_t)(level + 1) * kSubQueues * 32;
             uint32_t blocks = full_grid;
             if (level == 0 && blocks > (P.n_items / 64 + 3) / 4)
