@@ -63,7 +63,7 @@ constexpr uint32_t KIND_INTERNAL = 0, KIND_TRI = 1, KIND_MESH = 2, KIND_SPHERE =
 constexpr int kSubQueues = 64;             // a level's path queue is 64 sub-queues, each with its own append counter
 constexpr int kCounterSlots = 64, kCounterStride = 16; // statistics are added into 64 slots of 16 values, summed by the host
 constexpr int kMaxLevels = 64;             // bounce levels a wavefront trace can launch (bounce_limit <= 62)
-constexpr int kTailLevel = 3;               // from this bounce level on, one launch follows every remaining path to its end
+constexpr uint32_t kTailRays = 256u << 10;  // a level with no more rays than this follows every path to its end in one launch
 constexpr int kChunkSamples = 16;          // samples per pixel traced per wavefront chunk
 constexpr size_t kMaxItems = 48u << 20;    // work items (pixel samples) per chunk: bounds the queue workspace
 
@@ -81,7 +81,7 @@ struct KParams {
     unsigned long long *counters; // rays, box, tri, sph, tri_hits, replays
     uint32_t n_nodes;
     uint32_t n_fnodes;
-    int tail;         // k_path: follow every path of this launch to its end instead of queueing the next bounce
+    int tail;         // k_path: the last level (follow every path to its end; nothing is queued)
     int force_replay; // fast walk: resolve every ray by the ordered replay (verification aid)
     uint32_t n_my_tiles;
     int W, H, tiles_x;
@@ -1098,35 +1098,47 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
     // A level with too few rays to fill the chip is bound by the latency of one walk, which is shortest
     // when every lane walks alone; a level that saturates the chip is bound by throughput.
     const bool use_wave = WALK == WALK_WAVE && n_in >= P.wave_min_rays;
+    // Tail mode: when a level holds too few rays to fill the chip, its launch lasts as long as its single longest
+    // walk, and so would every launch after it; instead each lane then follows its path to the end, and the launches
+    // of the deeper levels find their queues empty and return at once.
+    const bool tail = P.tail != 0 || (P.level >= 1 && n_in <= kTailRays);
     // Batches of 64 items are dealt to the waves round-robin: one shared cursor would be hit by half a million
     // same-address atomics per launch at level 0, which alone takes longer than the rays.  Neighbouring
     // batches (the samples of one tile, tiles of one image row) go to different waves, so the expensive part of
     // the image is spread over the whole grid.
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // Level 0: batch b goes to wave b % n_waves (static; the work per batch is even enough and a shared cursor would
-    // be half a million same-address atomics).  Deeper levels: the waves with wave_id % 64 == q share sub-queue q and
-    // draw its batches from that sub-queue's own cursor, so a wave that met long walks simply draws fewer batches.
+    // Work distribution: the waves with wave_id % 64 == q form group q and draw batches from that group's own cursor
+    // (64 cursors in separate cache lines: atomics on one address are serialised at about 10 ns each), so a wave
+    // that met long walks simply draws fewer batches.  Level 0: group q owns the batches q, q + 64, q + 128, ... of
+    // camera rays and draws them kChunk at a time.  Deeper levels: group q owns sub-queue q.
+    constexpr uint32_t kChunk = 4u;
     const uint32_t my_q = wave_id & (uint32_t)(kSubQueues - 1);
     const uint32_t my_count = P.level == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sub_count, (int)my_q);
-    const uint32_t my_batches = (my_count + 63u) >> 6;
-    for (uint32_t turn = 0;; turn++) {
+    const uint32_t my_batches = P.level == 0 ? (n_batches > my_q ? (n_batches - my_q + (uint32_t)kSubQueues - 1u) / (uint32_t)kSubQueues : 0u)
+                                             : (my_count + 63u) >> 6;
+    const uint32_t chunk = P.level == 0 ? kChunk : 1u;
+    uint32_t next = 0u, left = 0u; // next batch of the group this wave may take, and how many of its chunk remain
+    for (;;) {
+        if (left == 0u) {
+            unsigned int b = 0;
+            if (lane == 0)
+                b = atomicAdd(P.sub_cursor + my_q * 32u, chunk);
+            next = __builtin_amdgcn_readfirstlane(b);
+            left = chunk;
+        }
+        const uint32_t b = next;
+        if (b >= my_batches)
+            break;
+        next++;
+        left--;
         uint32_t g, out_q; // g: item number (level 0) or record number in the queue; out_q: sub-queue continuing paths go to
         bool live;
         if (P.level == 0) {
-            const uint32_t batch = wave_id + turn * n_waves;
-            if (batch >= n_batches)
-                break;
+            const uint32_t batch = my_q + b * (uint32_t)kSubQueues;
             g = batch * 64u + lane;
             live = g < n_in;
-            out_q = batch & (uint32_t)(kSubQueues - 1);
+            out_q = my_q;
         } else {
-            unsigned int b = 0;
-            if (lane == 0)
-                b = atomicAdd(P.sub_cursor + my_q * 32u, 1u);
-            b = __builtin_amdgcn_readfirstlane(b);
-            if (b >= my_batches)
-                break;
             const uint32_t local = b * 64u + lane;
             live = local < my_count;
             g = my_q * P.sub_cap + local;
@@ -1183,11 +1195,11 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
         ended = false;
         if (live)
             ended = shade_path<OLD, STATS>(P, path, hit, cidx, cnt);
-        if (P.tail == 0)
+        if (!tail)
             break;
         live = live && !ended;
         }
-        if (P.tail != 0)
+        if (tail)
             continue;
         // ---- continuing paths go to the next level's queue, compacted per wave ----
         const bool cont = live && !ended;
@@ -1489,7 +1501,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         P.sub_cap = (((P.n_items + 63u) / 64u) / (uint32_t)kSubQueues + 66u) * 64u;
         for (int level = 0; level < levels; level++) {
             P.level = level;
-            P.tail = (level >= kTailLevel || level == levels - 1) ? 1 : 0;
+            P.tail = level == levels - 1 ? 1 : 0;
             P.q_in = ctx->d_q[level & 1];
             P.q_out = ctx->d_q[(level + 1) & 1];
             P.sub_in = ctx->d_levels + (size_t)level * kSubQueues * 32;
@@ -1517,8 +1529,6 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
             }
 #undef RT_LAUNCH_PATH
             RT_HIP_CHECK(ctx, hipGetLastError());
-            if (P.tail)
-                break;
         }
         hipLaunchKernelGGL(k_fold, dim3((unsigned)((npix + 255) / 256)), block, 0, ctx->stream, d_img, ctx->d_colors,
                            (uint32_t)npix, W, P.tiles_x, o.tile_rank, o.tile_world, P.chunk_first, s_now);
