@@ -1,0 +1,139 @@
+"""GPU parity on edge cases, through the C ABI, every traversal against the oracle, bit for bit:
+equal-distance ties (duplicated geometry: the reference keeps the first hit in ITS visiting order), rays with an
+exactly zero direction component whose origin lies exactly on box planes (0 * inf = NaN in the slab test,
+SimplifiedData.cpp:146-161), degenerate and sliver triangles, one- and two-leaf trees, tiny and ragged images,
+bounce limits 0 and 1."""
+import numpy as np
+import pytest
+
+from helpers import O, R, WL, bits, objparse, oracle_camera
+
+pytestmark = pytest.mark.gpu
+
+TRAVS = [R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_LANE, R.TRAV_WAVE, R.TRAV_NESTED]
+
+
+@pytest.fixture(scope="module")
+def tracer():
+    t = R.Tracer(0)
+    yield t
+    t.close()
+
+
+def both_scenes(models):
+    ps, os_ = R.SdScene(), O.SdScene()
+    for tris in models:
+        t = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 24)
+        ps.add_model(t)
+        os_.add_model(t, [len(t)])
+    ps.finalize()
+    os_.finalize()
+    return ps, os_
+
+
+def compare(tracer, ps, os_, cam, w, h, spp=2, bounce=8, seed=3, jitter=0.001, min_hits=1):
+    tracer.upload(ps)
+    tracer.set_camera(cam)
+    opt = O.make_options(bounce_limit=bounce, seed=seed, jitter=jitter, trig=O.TRIG_POLY)
+    oimg, oprim, ost = os_.render(oracle_camera(cam), opt, w, h, 1, spp, want_primary=True)
+    assert (oprim != R.MISS).sum() >= min_hits
+    for trav in TRAVS:
+        tracer.set_options(bounce_limit=bounce, seed=seed, jitter=jitter, collect_stats=True, traversal=trav)
+        img, prim, st = tracer.trace(w, h, 1, spp, want_primary=True)
+        assert np.count_nonzero(prim != oprim) == 0, trav
+        assert st.rays == ost.rays, trav
+        assert np.array_equal(bits(img), bits(oimg)), trav
+    return oprim
+
+
+def tri(p0, p1, p2, n=(0.0, 0.0, 1.0)):
+    return np.array([[*p0, *n, 0, 0], [*p1, *n, 0, 0], [*p2, *n, 0, 0]], dtype=np.float32).reshape(24)
+
+
+def test_equal_distance_ties_duplicated_geometry(tracer):
+    tris, _ = objparse.load_obj(WL.DRAGON_2426)
+    ps, os_ = both_scenes([tris, tris.copy(), tris.copy()])   # three coincident meshes: every hit is a three-way tie
+    compare(tracer, ps, os_, WL.DRAGON_2426_CAMERA, 320, 180, min_hits=2000)
+    # one mesh that holds every triangle twice, the second copies shuffled: which copy wins depends on where the
+    # reference's sort and median splits put them, and it is not always the same copy
+    perm = np.random.default_rng(1).permutation(len(tris))
+    ps, os_ = both_scenes([np.concatenate([tris, tris[perm]])])
+    prim = compare(tracer, ps, os_, WL.DRAGON_2426_CAMERA, 320, 180, min_hits=2000)
+    hit = prim[prim != R.MISS]
+    assert len(np.unique(hit // len(tris))) == 2
+
+
+def test_zero_direction_component_on_box_planes(tracer):
+    """Camera looks straight down -z; the middle pixel column has dir.x == 0 exactly, and the camera's x equals the
+    leaf boxes' pMin.x (vertex x minus the 1e-5 bias, in fp32), so (pMin.x - o.x) * (1 / 0) = 0 * inf = NaN."""
+    vx = np.float32(0.5)
+    on_plane = float(np.float32(vx - np.float32(1e-5)))
+    quads = []
+    for k, z in enumerate((0.0, -0.5, -1.0)):
+        quads.append(tri((vx, -1, z), (vx + 1, -1, z), (vx + 1, 1, z)))
+        quads.append(tri((vx, -1, z), (vx + 1, 1, z), (vx, 1, z)))
+        quads.append(tri((vx - 1, -1, z - 0.1), (vx, -1, z - 0.1), (vx, 1, z - 0.1)))
+    ps, os_ = both_scenes([np.stack(quads)])
+    cam = R.Camera(1.0, (on_plane, 0.0, 1.0), 2.0, 16.0 / 9.0, (on_plane, 0.0, 0.0))
+    compare(tracer, ps, os_, cam, 64, 36, spp=1, jitter=0.0, min_hits=100)
+    compare(tracer, ps, os_, cam, 64, 36, spp=3, jitter=0.001, min_hits=100)
+    cam_y = R.Camera(1.0, (1.0, 0.0, 1.0), 2.0, 16.0 / 9.0, (1.0, 0.0, 0.0))  # dir.y == 0 on the middle row as well
+    compare(tracer, ps, os_, cam_y, 64, 36, spp=1, jitter=0.0, min_hits=100)
+
+
+def test_degenerate_and_sliver_triangles(tracer):
+    rng = np.random.default_rng(5)
+    soup = []
+    for i in range(300):
+        c = rng.uniform(-1, 1, 3).astype(np.float32)
+        a, b = rng.normal(0, 0.3, 3).astype(np.float32), rng.normal(0, 0.3, 3).astype(np.float32)
+        kind = i % 6
+        if kind == 0:      # zero area: repeated vertex
+            soup.append(tri(c, c, c + a))
+        elif kind == 1:    # zero area: collinear
+            soup.append(tri(c, c + a, c + a * np.float32(2)))
+        elif kind == 2:    # sliver
+            soup.append(tri(c, c + a, c + a + b * np.float32(1e-6)))
+        else:
+            nrm = np.cross(a, b)
+            nrm = nrm / (np.linalg.norm(nrm) + 1e-20)
+            soup.append(tri(c, c + a, c + b, nrm))
+    ps, os_ = both_scenes([np.stack(soup)])
+    cam = R.Camera(1.0, (0.0, 0.0, 3.5), 2.0, 16.0 / 9.0, (0.0, 0.0, 0.0))
+    compare(tracer, ps, os_, cam, 200, 113, spp=2, min_hits=1000)
+    compare(tracer, ps, os_, R.Camera(1.0, (0.1, 0.05, 0.2), 2.0, 16.0 / 9.0, (0.0, 0.3, -1.0)), 160, 90, spp=2, min_hits=500)  # from inside
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_smallest_trees(tracer, n):
+    tris = [tri((-1, -1, -0.5 * k), (1, -1, -0.5 * k), (0, 1, -0.5 * k)) for k in range(n)]
+    ps, os_ = both_scenes([np.stack(tris)])
+    compare(tracer, ps, os_, R.Camera(1.0, (0.0, 0.0, 2.0), 2.0, 16.0 / 9.0, (0.0, 0.0, 0.0)), 96, 54, min_hits=200)
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 3), (9, 17), (65, 8)])
+def test_tiny_and_ragged_images(tracer, size):
+    tris, _ = objparse.load_obj(WL.DRAGON_2426)
+    ps, os_ = both_scenes([tris])
+    compare(tracer, ps, os_, WL.DRAGON_2426_CAMERA, size[0], size[1], spp=5, min_hits=0)
+
+
+@pytest.mark.parametrize("bounce", [0, 1, 2])
+def test_small_bounce_limits(tracer, bounce):
+    tris, _ = objparse.load_obj(WL.DRAGON_2426)
+    ps, os_ = both_scenes([tris])
+    compare(tracer, ps, os_, WL.DRAGON_2426_CAMERA, 160, 90, spp=3, bounce=bounce, min_hits=0 if bounce == 0 else 500)
+
+
+def test_many_samples_cross_chunks(tracer):
+    """More samples than one wavefront chunk holds (16), starting from a sample index > 1."""
+    tris, _ = objparse.load_obj(WL.DRAGON_2426)
+    ps, os_ = both_scenes([tris])
+    tracer.upload(ps)
+    tracer.set_camera(WL.DRAGON_2426_CAMERA)
+    tracer.set_options(bounce_limit=6, seed=8)
+    a, _, _ = tracer.trace(128, 72, 1, 5)
+    b, _, _ = tracer.trace(128, 72, 6, 40)
+    opt = O.make_options(bounce_limit=6, seed=8, trig=O.TRIG_POLY)
+    oimg, _, _ = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, 128, 72, 1, 45)
+    assert np.array_equal(bits(b), bits(oimg))

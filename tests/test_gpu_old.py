@@ -87,6 +87,22 @@ def test_two_meshes_metal_and_glass(tracer):
     _compare(tracer, ps, os_, cam, 320, 180, 4, 8, seed=5)
 
 
+def test_ties_and_rays_starting_inside(tracer):
+    """Duplicated spheres and a duplicated mesh (equal-distance ties: the first in the reference's visiting order
+    wins), concentric spheres, and a camera inside a large Lambertian sphere and inside a glass one (a ray that
+    starts inside never hits a non-dielectric sphere: near root only, Objects.hpp:57-60)."""
+    tris, _ = objparse.load_obj(WL.CYLINDER)
+    sp = WL.small_sphere_scene()
+    sp = sp + [sp[2], sp[3], sp[2]]                                       # exact duplicates
+    sp.append(((0.0, 1.0, 0.0), 0.5, R.MAT_METAL, (0.9, 0.9, 0.9, 1.0), 0.2))   # inside the glass sphere
+    sp.append(((13.0, 2.0, 3.0), 2.5, R.MAT_LAMBERTIAN, (0.3, 0.6, 0.3, 1.0), 0.0))  # around the first camera
+    meshes = [(tris, R.MAT_LAMBERTIAN, (0.8, 0.3, 0.3, 1.0), 0.0), (tris.copy(), R.MAT_METAL, (0.7, 0.7, 0.9, 1.0), 0.3)]
+    ps, os_ = product_old_scene(sp, meshes), oracle_old_scene(sp, meshes)
+    _compare(tracer, ps, os_, R.Camera(3.19, (13.0, 2.0, 3.0), 2.0, 16.0 / 9.0, (0.0, 0.5, 0.0)), 200, 113, 3, 8, seed=2)
+    _compare(tracer, ps, os_, R.Camera(1.0, (0.0, 1.0, 0.7), 2.0, 16.0 / 9.0, (4.0, 1.0, 0.0)), 200, 113, 3, 8, seed=4)   # inside the glass
+    _compare(tracer, ps, os_, R.Camera(1.0, (0.5, 1.5, 6.0), 2.0, 16.0 / 9.0, (0.0, 0.8, 0.0)), 33, 17, 2, 1, seed=6)
+
+
 def test_plugin_adaptors_drive_the_tracer(tracer):
     """RenderPipeline<SceneHIPContext, LoadSceneHIP, TraceSceneHIP> + headless TracerAsync: load once, one
     trace call per frame with sampleCount = 1, 2, 3 ... gives the n-sample running mean."""
