@@ -110,7 +110,9 @@ enum {
  *   replay procedure, which normally resolves only rays whose winning hit lies in front of its own leaf
  *   box's entry distance (a verification aid). */
 enum {
-    RT_TRAV_AUTO = 0,      /* = RT_TRAV_FAST */
+    RT_TRAV_AUTO = 0,      /* = RT_TRAV_FAST; = RT_TRAV_REFERENCE for an uploaded tree in which some interior box does not
+                              contain its children's boxes (the reference's builders never produce one; FAST is exact
+                              only for nested boxes and is refused for such a tree with RT_ERR_BAD_SCENE) */
     RT_TRAV_LANE = 1,      /* reference order; every lane follows its own index; node records through the vector memory path */
     RT_TRAV_WAVE = 2,      /* reference order; the wave advances together; node records through the scalar data path */
     RT_TRAV_NESTED = 3,    /* reference order; first-generation kernel: one 8x8 tile per wave, nested sample/bounce loops */

@@ -1282,6 +1282,7 @@ struct rt_ctx {
     float4 *d_nodes = nullptr, *d_tri_pos = nullptr, *d_tri_nrm = nullptr, *d_spheres = nullptr, *d_mats = nullptr;
     uint32_t n_nodes = 0;
     bool has_scene = false;
+    bool fast_exact = true; // the uploaded tree's interior boxes contain their children's (see build_layout)
     double expected_visits = 0.0; // sum of node box areas / root box area: nodes a random ray through the root meets
     rt_camera cam;
     bool has_camera = false;
@@ -1426,7 +1427,9 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     const bool st = o.collect_stats != 0;
     int trav = o.traversal;
     if (trav == RT_TRAV_AUTO)
-        trav = RT_TRAV_FAST;
+        trav = ctx->fast_exact ? RT_TRAV_FAST : RT_TRAV_REFERENCE;
+    if ((trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY) && !ctx->fast_exact)
+        return fail(ctx, RT_ERR_BAD_SCENE, "RT_TRAV_FAST needs a tree whose interior boxes contain their children's boxes");
     if (trav == RT_TRAV_REFERENCE)
         trav = ctx->expected_visits >= 512.0 ? RT_TRAV_WAVE : RT_TRAV_LANE;
     P.force_replay = trav == RT_TRAV_FAST_REPLAY ? 1 : 0;
@@ -1578,6 +1581,7 @@ struct SceneLayout {
     std::vector<float4> dn, fn, tp, tn, sp, mt; // reference-order nodes, fast-tree nodes, triangle positions / normals, spheres, materials
     uint32_t n_ref = 0, n_fast = 0, n_tri_slots = 0, n_sph_slots = 0;
     double expected_visits = 0.0;
+    bool nested = true; // every interior box of the caller's tree contains its children's boxes
 };
 
 int lfail(std::string &err, int code, const std::string &msg) {
@@ -1647,6 +1651,21 @@ int build_layout(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt
             size[p] = 1 + size[pos_of[nd.left]] + size[pos_of[nd.right]];
         else if (nd.flags == RT_NODE_MESH)
             size[p] = 1 + size[pos_of[nd.left]];
+    }
+    // The fast walk reproduces the reference's result only if every interior box contains the boxes of its children
+    // (then a leaf that passes its own slab test has ancestors that passed theirs).  The reference's builders
+    // guarantee it; a caller's hand-made tree may not, and is then walked in reference order only.
+    L.nested = true;
+    for (uint32_t p = 0; p < m && L.nested; p++) {
+        const rt_node &nd = nodes[order_of[p]];
+        if (nd.flags != RT_NODE_INTERNAL)
+            continue;
+        for (const uint32_t child : {nd.left, nd.right}) {
+            const rt_node &c = nodes[child];
+            for (int k = 0; k < 3; k++)
+                if (!(nd.pmin[k] <= c.pmin[k]) || !(nd.pmax[k] >= c.pmax[k]))
+                    L.nested = false;
+        }
     }
     // 3. The fast tree: a surface-area-heuristic hierarchy over the reference's leaf boxes (see fast_bvh.hpp).
     //    Scene-level leaves (triangles of the flat scene, spheres, mesh objects) form the top tree; the
@@ -1917,6 +1936,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_
         return rc;
     }
     ctx->expected_visits = L.expected_visits;
+    ctx->fast_exact = L.nested;
     ctx->n_nodes = L.n_ref;
     ctx->n_fnodes = L.n_fast;
     ctx->has_scene = true;

@@ -179,6 +179,29 @@ def test_full_size_properties_fast_vs_reference_order(tracer):
     assert np.isfinite(fi).all() and fi.min() >= 0.0 and fi[..., 3].max() <= 1.0
 
 
+def test_hand_made_tree_with_boxes_that_do_not_nest(tracer):
+    """The fast walk is exact only when interior boxes contain their children's.  A tree that breaks this (here: the
+    root's box shrunk to half the model) is walked in reference order by RT_TRAV_AUTO and refused by RT_TRAV_FAST."""
+    sc = product_sd_scene([WL.DRAGON_2426])
+    nodes, tris = sc.nodes().copy(), sc.tris()
+    tracer.upload_arrays(nodes, sc.root, tris, np.zeros(0), np.zeros(0), sc.order)
+    tracer.set_camera(WL.DRAGON_2426_CAMERA)
+    tracer.set_options(bounce_limit=2, seed=4)
+    good, gprim, _ = tracer.trace(192, 108, 1, 2, want_primary=True)
+    nodes["pmax"][sc.root][0] = 0.0   # the root now excludes everything at x > 0
+    tracer.upload_arrays(nodes, sc.root, tris, np.zeros(0), np.zeros(0), sc.order)
+    tracer.set_options(bounce_limit=2, seed=4)                              # AUTO
+    auto, aprim, _ = tracer.trace(192, 108, 1, 2, want_primary=True)
+    tracer.set_options(bounce_limit=2, seed=4, traversal=R.TRAV_LANE)
+    lane, lprim, _ = tracer.trace(192, 108, 1, 2, want_primary=True)
+    assert np.array_equal(aprim, lprim) and np.array_equal(bits(auto), bits(lane))
+    assert np.count_nonzero(aprim != gprim) > 100                           # the shrunk box does change the result
+    tracer.set_options(bounce_limit=2, seed=4, traversal=R.TRAV_FAST)
+    with pytest.raises(R.TracerError) as e:
+        tracer.trace(192, 108, 1, 2)
+    assert e.value.code == -5
+
+
 def test_errors(tracer):
     t2 = R.Tracer(0)
     t2.set_camera(WL.DEFAULT_CAMERA)
