@@ -118,7 +118,9 @@ enum {
     RT_TRAV_NESTED = 3,    /* reference order; first-generation kernel: one 8x8 tile per wave, nested sample/bounce loops */
     RT_TRAV_FAST = 4,
     RT_TRAV_FAST_REPLAY = 5,
-    RT_TRAV_REFERENCE = 6  /* reference order; LANE or WAVE chosen from a surface-area estimate of the visits per ray */
+    RT_TRAV_REFERENCE = 6, /* reference order; LANE or WAVE chosen from a surface-area estimate of the visits per ray */
+    RT_TRAV_FAST_REFILL = 7 /* FAST with lane re-fill (a lane that finishes its walk takes the next ray instead of waiting
+                               for its wave); RT_TRAV_FAST itself uses it for scenes larger than the L2s */
 };
 
 typedef struct rt_options {

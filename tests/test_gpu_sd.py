@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 # per-lane walk, the first-generation nested-loop kernel (these three perform the reference's own tests, so
 # their test counts equal the oracle's too), the fast walk over the device's own hierarchy, and the fast
 # walk with every ray forced through its ordered replay
-TRAVS = [R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED, R.TRAV_FAST, R.TRAV_FAST_REPLAY]
+TRAVS = [R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED, R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL]
 REFERENCE_ORDER = (R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED)
 
 
