@@ -123,9 +123,14 @@ def main():
     # One render = `n` steps of `spp` samples accumulated into the running mean on the device (the reference's
     # progressive sampleCount protocol, Renderer/TracerImpl.cpp:9-12), then -- N > 1 -- ONE RCCL reduce(SUM) of the
     # per-rank means, / world on rank 0.  Rank r draws the sample indices r * n * spp + 1 ... (r + 1) * n * spp.
+    # The steps are issued back to back with pipelining on: the tracer overlaps the latency-bound end of one step (deep
+    # bounce levels) with the start of the next on its own streams; rt_join orders the image before the reduce.
+    tr.set_pipelining(True)
+
     def render(n):
         for i in range(n):
             tr.trace_device(W, H, 1 + i * spp, spp, img.data_ptr())
+        tr.join()
         P.combine_sample_split(img, dst=0)
 
     # work of one trace call: counted once, untimed, by the counting variant of the same kernel

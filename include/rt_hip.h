@@ -146,7 +146,8 @@ typedef struct rt_stats {
     uint64_t replays;   /* RT_TRAV_FAST: rays resolved by the ordered replay (always counted) */
     float kernel_ms;     /* HIP-event time of the last trace kernel on the context's stream */
     float total_ms;      /* host wall time of the call (rt_trace only) */
-    float kernel_ms_sum; /* HIP-event time summed over the launches since the previous sync */
+    float kernel_ms_sum; /* HIP-event time summed over the calls since the previous sync; with pipelining on, the time
+                            from the first call's start to the last call's end */
     uint32_t launches;   /* number of those launches */
 } rt_stats;
 
@@ -188,6 +189,15 @@ int rt_trace(rt_ctx *ctx, int width, int height, int first_sample, int n_samples
  * NULL).  Enqueued on the context's stream; nothing is copied to the host. */
 int rt_trace_device(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *d_rgba,
                     uint32_t *d_primary_id);
+/* Lets consecutive rt_trace_device calls overlap (off by default).  Internally the tracer works in chunks on two
+ * streams of its own so that the latency-bound end of one chunk overlaps the start of the next; by default every call
+ * ends by making the context's stream wait for its chunks, which keeps the ordering promise above but lets nothing
+ * overlap ACROSS calls.  With pipelining on, a call returns with its chunks ordered only among themselves (the folds
+ * into the running mean stay in sample order); the caller orders the results with rt_join -- the context's stream
+ * then waits for everything issued so far (a stream-level wait: the host does not block) -- or with rt_sync.  This is
+ * for callers that issue many passes back to back (progressive rendering, bench.py); no reference counterpart. */
+int rt_set_pipelining(rt_ctx *ctx, int on);
+int rt_join(rt_ctx *ctx);
 /* Replaces the context's stream with a caller-owned hipStream_t (NULL = the default stream). */
 int rt_set_stream(rt_ctx *ctx, void *hip_stream);
 /* Waits for the context's stream and reports the counters and kernel time of the last trace. */

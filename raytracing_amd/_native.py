@@ -59,7 +59,7 @@ assert C.sizeof(Node) == 36 and C.sizeof(Tri) == 100 and C.sizeof(Sphere) == 24 
 # every symbol include/rt_hip.h declares
 HIP_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_set_options",
                "rt_reset", "rt_trace", "rt_trace_device", "rt_set_stream", "rt_sync", "rt_version", "rt_layout_scene",
-               "rt_layout_free"]
+               "rt_layout_free", "rt_set_pipelining", "rt_join"]
 
 _hip = None
 _host = None
@@ -87,6 +87,8 @@ def hip():
         L.rt_trace_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.rt_set_stream.argtypes = [vp, vp]
         L.rt_sync.argtypes = [vp, C.POINTER(StatsC)]
+        L.rt_set_pipelining.argtypes = [vp, C.c_int]
+        L.rt_join.argtypes = [vp]
         L.rt_version.restype = C.c_char_p
         L.rt_layout_scene.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, C.c_int,
                                       C.POINTER(LayoutViewC)]

@@ -1512,9 +1512,22 @@ struct rt_ctx {
     int num_cus = 0;
     int blocks_per_cu[16] = {0}; // [nested | wavefront per-lane | wavefront wave-sync | wavefront fast][estimator][stats]
     // wavefront workspace: per-sample colour buffer, two ping-pong path queues, per-level cursors/counters
-    float4 *d_colors = nullptr, *d_q[2] = {nullptr, nullptr};
-    unsigned int *d_levels = nullptr; // [2 * kMaxLevels]: cursor[l], count[l]
-    size_t colors_cap = 0, q_cap = 0; // capacities in float4 / records
+    // Two pipes take the chunks of the wavefront tracer in turn, each with its own stream and workspace, so that the
+    // latency-bound end of one chunk (deep bounce levels: few rays, long walks) overlaps the throughput-bound start of
+    // the next.  The folds into the running mean are chained by events and stay in sample order.
+    struct Pipe {
+        hipStream_t stream = nullptr;
+        float4 *d_colors = nullptr, *d_q[2] = {nullptr, nullptr};
+        unsigned int *d_levels = nullptr; // per level: 64 sub-queue slots of 32 words (count, batch cursor)
+        size_t colors_cap = 0, q_cap = 0; // capacities in float4 / records
+        hipEvent_t done = nullptr;        // recorded after the pipe's last fold
+        bool used = false;                // `done` has been recorded at least once
+    } pipes[2];
+    int next_pipe = 0;
+    hipEvent_t ev_start = nullptr;  // orders a call's chunks after what precedes the call on the context's stream
+    hipEvent_t last_fold = nullptr; // `done` of the pipe that ran the latest fold
+    bool pipelining = false;        // rt_set_pipelining: calls may overlap; rt_join / rt_sync order their results
+    bool joined = true;             // the context's stream has been made to wait for both pipes
 };
 
 namespace {
@@ -1581,6 +1594,25 @@ template <int KERNEL, bool OLD, bool STATS> int occupancy(int *out) {
         n = 8;
     *out = n;
     return 0;
+}
+
+// The context's stream waits (stream-level, the host does not) for everything the pipes have been given.
+int join_pipes(rt_ctx *ctx) {
+    if (!ctx->joined) {
+        for (auto &pp : ctx->pipes)
+            if (pp.used)
+                RT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, pp.done, 0));
+        ctx->joined = true;
+    }
+    return RT_OK;
+}
+int sync_all(rt_ctx *ctx) {
+    for (auto &pp : ctx->pipes)
+        if (pp.stream)
+            RT_HIP_CHECK(ctx, hipStreamSynchronize(pp.stream));
+    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->joined = true;
+    return RT_OK;
 }
 
 int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim) {
@@ -1664,6 +1696,11 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     }
     dim3 block(256);
     if (trav == RT_TRAV_NESTED) {
+        {
+            const int jrc = join_pipes(ctx); // earlier pipelined calls may still be folding into this image
+            if (jrc != RT_OK)
+                return jrc;
+        }
         uint32_t blocks = full_grid;
         if (blocks > (P.n_my_tiles + 3) / 4)
             blocks = (P.n_my_tiles + 3) / 4;
@@ -1694,28 +1731,33 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     // level 0, or of every 64th batch of each of this level's 64 sub-queues; no level has more batches than level 0
     // has plus one partial batch per sub-queue, so (n_batches / 64 + 66) * 64 records per sub-queue always suffice
     const size_t need_colors = (size_t)S * npix, need_q = (size_t)S * items_per_sample + (size_t)kSubQueues * 66 * 64;
-    if (need_colors > ctx->colors_cap || need_q > ctx->q_cap) {
-        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_colors) (void)hipFree(ctx->d_colors);
-        if (ctx->d_q[0]) (void)hipFree(ctx->d_q[0]);
-        if (ctx->d_q[1]) (void)hipFree(ctx->d_q[1]);
-        ctx->d_colors = ctx->d_q[0] = ctx->d_q[1] = nullptr;
-        ctx->colors_cap = ctx->q_cap = 0;
-        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_colors, need_colors * sizeof(float4)));
-        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_q[0], (need_q ? need_q : 1) * 4 * sizeof(float4)));
-        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_q[1], (need_q ? need_q : 1) * 4 * sizeof(float4)));
-        ctx->colors_cap = need_colors;
-        ctx->q_cap = need_q;
-    }
     const int levels = old ? o.bounce_limit + 1 : (o.bounce_limit > 1 ? o.bounce_limit : 1);
-    P.colors = ctx->d_colors;
     P.npix = (uint32_t)npix;
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    hipStream_t last_stream = ctx->stream;
     for (int done = 0; done < count || (count == 0 && done == 0); done += S) {
         const int s_now = count - done < S ? count - done : S;
         if (s_now <= 0)
             break;
-        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_levels, 0, (size_t)(levels + 1) * kSubQueues * 32 * sizeof(unsigned int), ctx->stream));
+        rt_ctx::Pipe &pp = ctx->pipes[ctx->next_pipe];
+        ctx->next_pipe ^= 1;
+        if (need_colors > pp.colors_cap || need_q > pp.q_cap) {
+            RT_HIP_CHECK(ctx, hipStreamSynchronize(pp.stream));
+            if (pp.d_colors) (void)hipFree(pp.d_colors);
+            if (pp.d_q[0]) (void)hipFree(pp.d_q[0]);
+            if (pp.d_q[1]) (void)hipFree(pp.d_q[1]);
+            pp.d_colors = pp.d_q[0] = pp.d_q[1] = nullptr;
+            pp.colors_cap = pp.q_cap = 0;
+            RT_HIP_CHECK(ctx, hipMalloc((void **)&pp.d_colors, need_colors * sizeof(float4)));
+            RT_HIP_CHECK(ctx, hipMalloc((void **)&pp.d_q[0], (need_q ? need_q : 1) * 4 * sizeof(float4)));
+            RT_HIP_CHECK(ctx, hipMalloc((void **)&pp.d_q[1], (need_q ? need_q : 1) * 4 * sizeof(float4)));
+            pp.colors_cap = need_colors;
+            pp.q_cap = need_q;
+        }
+        RT_HIP_CHECK(ctx, hipStreamWaitEvent(pp.stream, ctx->ev_start, 0));
+        RT_HIP_CHECK(ctx, hipMemsetAsync(pp.d_levels, 0, (size_t)(levels + 1) * kSubQueues * 32 * sizeof(unsigned int), pp.stream));
+        P.colors = pp.d_colors;
         P.S = s_now;
         P.chunk_first = first + done;
         P.n_items = (uint32_t)((size_t)s_now * items_per_sample);
@@ -1723,11 +1765,11 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         for (int level = 0; level < levels; level++) {
             P.level = level;
             P.tail = level == levels - 1 ? 1 : 0;
-            P.q_in = ctx->d_q[level & 1];
-            P.q_out = ctx->d_q[(level + 1) & 1];
-            P.sub_in = ctx->d_levels + (size_t)level * kSubQueues * 32;
-            P.sub_cursor = ctx->d_levels + (size_t)level * kSubQueues * 32 + 1;
-            P.sub_out = ctx->d_levels + (size_t)(level + 1) * kSubQueues * 32;
+            P.q_in = pp.d_q[level & 1];
+            P.q_out = pp.d_q[(level + 1) & 1];
+            P.sub_in = pp.d_levels + (size_t)level * kSubQueues * 32;
+            P.sub_cursor = pp.d_levels + (size_t)level * kSubQueues * 32 + 1;
+            P.sub_out = pp.d_levels + (size_t)(level + 1) * kSubQueues * 32;
             uint32_t blocks = full_grid;
             if (level == 0 && blocks > (P.n_items / 64 + 3) / 4)
                 blocks = (P.n_items / 64 + 3) / 4;
@@ -1738,10 +1780,10 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
             // fetch latency; the spills land in the shading code, which runs once per ray); the others: uncapped
 #define RT_LAUNCH_PATH(OLD_, STATS_)                                                                                  \
     do {                                                                                                              \
-        if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, 0, ctx->stream, P);   \
-        else if (walk == WALK_FAST && refill) hipLaunchKernelGGL((k_refill<OLD_, STATS_>), grid, block, 0, ctx->stream, P); \
-        else if (walk == WALK_FAST) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_FAST>), grid, block, 0, ctx->stream, P); \
-        else hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_LANE>), grid, block, 0, ctx->stream, P);                     \
+        if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, 0, pp.stream, P);     \
+        else if (walk == WALK_FAST && refill) hipLaunchKernelGGL((k_refill<OLD_, STATS_>), grid, block, 0, pp.stream, P); \
+        else if (walk == WALK_FAST) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_FAST>), grid, block, 0, pp.stream, P); \
+        else hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_LANE>), grid, block, 0, pp.stream, P);                       \
     } while (0)
             switch (variant) {
             case 4: RT_LAUNCH_PATH(false, false); break;
@@ -1752,17 +1794,35 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
 #undef RT_LAUNCH_PATH
             RT_HIP_CHECK(ctx, hipGetLastError());
         }
-        hipLaunchKernelGGL(k_fold, dim3((unsigned)((npix + 255) / 256)), block, 0, ctx->stream, d_img, ctx->d_colors,
+        // the running mean takes the samples in order: this fold waits for the one before it, whichever pipe ran it
+        if (ctx->last_fold != nullptr && ctx->last_fold != pp.done)
+            RT_HIP_CHECK(ctx, hipStreamWaitEvent(pp.stream, ctx->last_fold, 0));
+        hipLaunchKernelGGL(k_fold, dim3((unsigned)((npix + 255) / 256)), block, 0, pp.stream, d_img, pp.d_colors,
                            (uint32_t)npix, W, P.tiles_x, o.tile_rank, o.tile_world, P.chunk_first, s_now);
         RT_HIP_CHECK(ctx, hipGetLastError());
+        RT_HIP_CHECK(ctx, hipEventRecord(pp.done, pp.stream));
+        pp.used = true;
+        ctx->last_fold = pp.done;
+        ctx->joined = false;
+        last_stream = pp.stream;
     }
-    RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].second, ctx->stream));
+    if (!ctx->pipelining) { // the call's results are ordered on the context's stream, as documented
+        int jrc = join_pipes(ctx);
+        if (jrc != RT_OK)
+            return jrc;
+        last_stream = ctx->stream;
+    }
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].second, last_stream));
     ctx->pending++;
     return RT_OK;
 }
 
 int sync_and_stats(rt_ctx *ctx, rt_stats *stats) {
-    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        const int src = sync_all(ctx);
+        if (src != RT_OK)
+            return src;
+    }
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         if (ctx->pending > 0) {
@@ -1785,6 +1845,8 @@ int sync_and_stats(rt_ctx *ctx, rt_stats *stats) {
                 sum += ms;
             }
             stats->kernel_ms = ms;
+            if (ctx->pipelining) // calls overlap: the time they took together, first start to last end
+                RT_HIP_CHECK(ctx, hipEventElapsedTime(&sum, ctx->events[0].first, ctx->events[ctx->pending - 1].second));
             stats->kernel_ms_sum = sum;
             stats->launches = (uint32_t)ctx->pending;
         }
@@ -2080,7 +2142,12 @@ int rt_create(rt_ctx **out, int device) {
     if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) return bail("hipMalloc");
     if (hipMalloc((void **)&ctx->d_counters, kCounterSlots * kCounterStride * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc");
     if (hipMemset(ctx->d_counters, 0, kCounterSlots * kCounterStride * sizeof(unsigned long long)) != hipSuccess) return bail("hipMemset");
-    if (hipMalloc((void **)&ctx->d_levels, (size_t)(kMaxLevels + 1) * kSubQueues * 32 * sizeof(unsigned int)) != hipSuccess) return bail("hipMalloc");
+    if (hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
+    for (auto &pp : ctx->pipes) {
+        if (hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
+        if (hipEventCreateWithFlags(&pp.done, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
+        if (hipMalloc((void **)&pp.d_levels, (size_t)(kMaxLevels + 1) * kSubQueues * 32 * sizeof(unsigned int)) != hipSuccess) return bail("hipMalloc");
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail("hipGetDeviceProperties");
     ctx->num_cus = prop.multiProcessorCount;
@@ -2108,6 +2175,9 @@ void rt_destroy(rt_ctx *ctx) {
     if (!ctx)
         return;
     (void)hipSetDevice(ctx->device);
+    for (auto &pp : ctx->pipes)
+        if (pp.stream)
+            (void)hipStreamSynchronize(pp.stream);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
@@ -2115,10 +2185,15 @@ void rt_destroy(rt_ctx *ctx) {
     if (ctx->d_primary) (void)hipFree(ctx->d_primary);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-    if (ctx->d_levels) (void)hipFree(ctx->d_levels);
-    if (ctx->d_colors) (void)hipFree(ctx->d_colors);
-    if (ctx->d_q[0]) (void)hipFree(ctx->d_q[0]);
-    if (ctx->d_q[1]) (void)hipFree(ctx->d_q[1]);
+    for (auto &pp : ctx->pipes) {
+        if (pp.d_levels) (void)hipFree(pp.d_levels);
+        if (pp.d_colors) (void)hipFree(pp.d_colors);
+        if (pp.d_q[0]) (void)hipFree(pp.d_q[0]);
+        if (pp.d_q[1]) (void)hipFree(pp.d_q[1]);
+        if (pp.done) (void)hipEventDestroy(pp.done);
+        if (pp.stream) (void)hipStreamDestroy(pp.stream);
+    }
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     for (auto &e : ctx->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -2144,7 +2219,11 @@ int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_
     }
     const std::vector<float4> &dn = L.dn, &fn = L.fn, &tp = L.tp, &tn = L.tn, &sp = L.sp, &mt = L.mt;
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        const int src = sync_all(ctx); // nothing may still be walking the old scene
+        if (src != RT_OK)
+            return src;
+    }
     free_scene(ctx);
     int rc;
     if ((rc = upload(ctx, &ctx->d_nodes, dn)) != RT_OK || (rc = upload(ctx, &ctx->d_fnodes, fn)) != RT_OK ||
@@ -2189,6 +2268,11 @@ int rt_reset(rt_ctx *ctx) {
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(ctx->mu);
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    {
+        const int jrc = join_pipes(ctx);
+        if (jrc != RT_OK)
+            return jrc;
+    }
     if (ctx->d_image)
         RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_image, 0, (size_t)ctx->img_w * ctx->img_h * sizeof(float4), ctx->stream));
     return RT_OK;
@@ -2204,6 +2288,11 @@ int rt_trace(rt_ctx *ctx, int width, int height, int first_sample, int n_samples
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad width/height");
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t px = (size_t)width * (size_t)height;
+    {
+        const int jrc = join_pipes(ctx); // the image may still be the target of pipelined calls
+        if (jrc != RT_OK)
+            return jrc;
+    }
     if (width != ctx->img_w || height != ctx->img_h || !ctx->d_image) {
         RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_image) (void)hipFree(ctx->d_image);
@@ -2222,6 +2311,9 @@ int rt_trace(rt_ctx *ctx, int width, int height, int first_sample, int n_samples
     if (out_primary_id)
         RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_primary, 0xFF, px * sizeof(uint32_t), ctx->stream));
     int rc = launch_trace(ctx, width, height, first_sample, n_samples, ctx->d_image, out_primary_id ? ctx->d_primary : nullptr);
+    if (rc != RT_OK)
+        return rc;
+    rc = join_pipes(ctx);
     if (rc != RT_OK)
         return rc;
     if (out_rgba_mean)
@@ -2250,12 +2342,36 @@ int rt_set_stream(rt_ctx *ctx, void *hip_stream) {
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(ctx->mu);
     RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        const int src = sync_all(ctx);
+        if (src != RT_OK)
+            return src;
+    }
     if (ctx->own_stream && ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     return RT_OK;
+}
+
+int rt_set_pipelining(rt_ctx *ctx, int on) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const int jrc = join_pipes(ctx);
+    if (jrc != RT_OK)
+        return jrc;
+    ctx->pipelining = on != 0;
+    return RT_OK;
+}
+
+int rt_join(rt_ctx *ctx) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return join_pipes(ctx);
 }
 
 int rt_sync(rt_ctx *ctx, rt_stats *stats) {

@@ -118,6 +118,12 @@ class Tracer:
     def set_stream(self, stream_ptr):
         self._check(N.hip().rt_set_stream(self._ctx, stream_ptr))
 
+    def set_pipelining(self, on):
+        self._check(N.hip().rt_set_pipelining(self._ctx, 1 if on else 0))
+
+    def join(self):
+        self._check(N.hip().rt_join(self._ctx))
+
     def sync(self):
         st = N.StatsC()
         self._check(N.hip().rt_sync(self._ctx, C.byref(st)))

@@ -137,3 +137,49 @@ def test_many_samples_cross_chunks(tracer):
     opt = O.make_options(bounce_limit=6, seed=8, trig=O.TRIG_POLY)
     oimg, _, _ = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, 128, 72, 1, 45)
     assert np.array_equal(bits(b), bits(oimg))
+
+
+def test_more_samples_than_one_chunk_holds(tracer):
+    """130 samples of a small image = three chunks (64 + 64 + 2), which the tracer runs alternately on its two
+    internal streams; the folds into the running mean must stay in sample order."""
+    tris, _ = objparse.load_obj(WL.CYLINDER)
+    ps, os_ = both_scenes([tris])
+    cam = R.Camera(1.0, (0.5, 1.5, 6.0), 2.0, 16.0 / 9.0, (0.0, 0.8, 0.0))
+    tracer.upload(ps)
+    tracer.set_camera(cam)
+    tracer.set_options(bounce_limit=4, seed=12)
+    img, _, _ = tracer.trace(96, 54, 1, 130)
+    oimg, _, _ = os_.render(oracle_camera(cam), O.make_options(bounce_limit=4, seed=12, trig=O.TRIG_POLY), 96, 54, 1, 130)
+    assert np.array_equal(bits(img), bits(oimg))
+
+
+def test_pipelined_device_calls(tracer):
+    """rt_set_pipelining: consecutive rt_trace_device calls overlap on the tracer's own streams; rt_join / rt_sync
+    order the result.  Seven progressive calls of 3 samples each into a caller-owned device image must give the
+    21-sample running mean, bit for bit, and the call after switching pipelining off again must see it too."""
+    torch = pytest.importorskip("torch")
+    tris, _ = objparse.load_obj(WL.DRAGON_2426)
+    ps, os_ = both_scenes([tris])
+    t = R.Tracer(0)
+    t.upload(ps)
+    t.set_camera(WL.DRAGON_2426_CAMERA)
+    t.set_options(bounce_limit=8, seed=21)
+    w, h = 200, 113
+    img = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    t.set_pipelining(True)
+    for i in range(7):
+        t.trace_device(w, h, 1 + 3 * i, 3, img.data_ptr())
+    t.join()
+    st = t.sync()
+    assert st.launches == 7
+    opt = O.make_options(bounce_limit=8, seed=21, trig=O.TRIG_POLY)
+    oimg, _, ost = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, w, h, 1, 21)
+    assert st.rays == ost.rays
+    assert np.array_equal(bits(img.cpu().numpy()), bits(oimg))
+    t.set_pipelining(False)
+    t.trace_device(w, h, 22, 2, img.data_ptr())
+    t.sync()
+    oimg2, _, _ = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, w, h, 1, 23)
+    assert np.array_equal(bits(img.cpu().numpy()), bits(oimg2))
+    t.close()
