@@ -103,6 +103,27 @@ def test_ties_and_rays_starting_inside(tracer):
     _compare(tracer, ps, os_, R.Camera(1.0, (0.5, 1.5, 6.0), 2.0, 16.0 / 9.0, (0.0, 0.8, 0.0)), 33, 17, 2, 1, seed=6)
 
 
+def test_full_size_fast_vs_reference_order(tracer):
+    """At the benchmark's full size (485 spheres, 1080p) the oracle is too slow to be the checker; the fast walk, its
+    re-fill variant and the reference-order walk are independent implementations and must agree bit for bit.  The
+    spheres touch their boxes, so this frame also sends thousands of rays through the ordered replay."""
+    ps = product_old_scene(WL.rtiow_spheres())
+    tracer.upload(ps)
+    tracer.set_camera(WL.RTIOW_CAMERA)
+    out = {}
+    for trav in (R.TRAV_FAST, R.TRAV_FAST_REFILL, R.TRAV_LANE):
+        tracer.set_options(bounce_limit=8, estimator=R.EST_OLD_RECURSIVE, seed=42, traversal=trav)
+        out[trav] = tracer.trace(1920, 1080, 1, 3, want_primary=True)
+    fi, fp, fs = out[R.TRAV_FAST]
+    assert fs.replays > 100
+    for trav in (R.TRAV_FAST_REFILL, R.TRAV_LANE):
+        oi, op, os2 = out[trav]
+        assert fs.rays == os2.rays
+        assert np.array_equal(fp, op)
+        assert np.array_equal(bits(fi), bits(oi))
+    assert np.isfinite(fi).all() and fi.min() >= 0.0
+
+
 def test_plugin_adaptors_drive_the_tracer(tracer):
     """RenderPipeline<SceneHIPContext, LoadSceneHIP, TraceSceneHIP> + headless TracerAsync: load once, one
     trace call per frame with sampleCount = 1, 2, 3 ... gives the n-sample running mean."""
