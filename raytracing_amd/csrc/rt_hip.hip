@@ -11,12 +11,21 @@
 // fused multiply-add (build with -ffp-contract=off) and correctly rounded divide and sqrt, so hit
 // primitives, hit distances and shaded pixels are reproducible bit for bit on a CPU.
 //
-// Traversal design: the reference visits nodes in one fixed depth-first order that does not depend on
-// the ray (children are never sorted by distance).  The scene is therefore re-laid in HBM in exactly
-// that visiting order as 32-byte records {pMin, pMax, skip, kind}; "descend" is index+1 and "prune"
-// is a jump to the record's skip index, so a lane needs no traversal stack at all and performs
-// exactly the slab and triangle tests the reference performs, in the same order, with the same
-// running closest distance.
+// Traversal design.  The reference visits nodes in one fixed depth-first order that does not depend on the ray
+// (children are never sorted by distance), and its interior boxes only prune: what it returns is decided by the
+// leaf boxes, the primitive tests and the order in which leaves are met.  Two node arrays are therefore laid out
+// in HBM, both as 32-byte records {box, skip, word} in depth-first pre-order, where "descend" is the next record and
+// "prune" is a jump to the record's skip offset, so that no lane needs a traversal stack:
+//   * the reference's own tree in the reference's own visiting order -- the walks over it (closest_hit,
+//     closest_hit_wave, k_trace) perform exactly the reference's slab and triangle tests, in the same order, with
+//     the same running closest distance;
+//   * the fast tree (fast_bvh.hpp): a surface-area-heuristic hierarchy of exact unions over the reference's leaf
+//     boxes, kept bit for bit.  closest_hit_fast walks it without closest-distance pruning, keeps the smallest
+//     (t, position in the reference's order) and so returns the reference's hit from far fewer tests; the rare ray
+//     whose winner lies in front of its own leaf box is resolved by replay_ordered.  This is the default.
+// The tracer is a wavefront: one launch per bounce level (k_path, or k_refill for scenes larger than the L2s),
+// paths of every depth compacted into full waves, per-sample colours folded into the running mean in sample order
+// (k_fold).
 
 #include <hip/hip_runtime.h>
 
