@@ -1113,9 +1113,8 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
     const uint32_t lane = threadIdx.x & 63u;
     Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     // Level 0: items are camera rays, batch b = items 64 b .. 64 b + 63.  Deeper levels: the queue is kSubQueues
-    // sub-queues (sub-queue q = the paths appended by batches b with b % 64 == q of the level before); lane q of
-    // every wave reads count q, a wave scan turns the counts into batch ranges, and batch b of this level is looked
-    // up with one ballot.
+    // sub-queues, each filled by the level before through its own append counter; lane q of every wave reads count
+    // q, and a wave scan gives the level's total number of batches (for the tail decision and the early return).
     uint32_t sub_count = 0u, sub_end = 0u; // lane q: records in sub-queue q; batches in sub-queues 0..q
     uint32_t n_batches;
     if (P.level == 0) {
