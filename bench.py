@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dragon18520_1080p")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (0 = the workload's)")
+    ap.add_argument("--traversal", type=int, default=4, help="RT_TRAV_* of the timed steps (4 = fast walk, 7 = with lane re-fill)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-counts", action="store_true",
                     help="skip the untimed pass that counts the tests of the reference-order walk")
@@ -115,7 +116,7 @@ def main():
     tr.set_stream(torch.cuda.current_stream().cuda_stream)
     img = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
 
-    def options(stats, traversal=R.TRAV_FAST):
+    def options(stats, traversal=args.traversal):
         tr.set_options(bounce_limit=wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
                        collect_stats=stats, sample_offset=P.sample_offset(rank, spp * max(args.steps, args.warmup)),
                        traversal=traversal)
