@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "librt_oracle.so")
 
 TRIG_LIBM, TRIG_POLY = 0, 1
-TRAV_LOOP, TRAV_RECURSIVE, TRAV_BRUTE = 0, 1, 2
+TRAV_LOOP, TRAV_RECURSIVE, TRAV_BRUTE, TRAV_LEAVES = 0, 1, 2, 3
 ACCUM_RECURSIVE, ACCUM_FORWARD = 0, 1
 MAT_LAMBERTIAN, MAT_METAL, MAT_EMIT, MAT_DIELECTRIC = 0, 1, 2, 4
 MISS = 0xFFFFFFFF
@@ -280,3 +280,9 @@ def cosine_dir(normal, u1, u2, trig):
     out = np.zeros(3, dtype=np.float32)
     lib().ora_cosine_dir(np_, u1, u2, trig, out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
+
+
+def take_leaf_replays():
+    """Rays TRAV_LEAVES resolved by its ordered replay since the last call."""
+    lib().ora_take_leaf_replays.restype = C.c_uint64
+    return int(lib().ora_take_leaf_replays())

@@ -21,6 +21,7 @@
 #include "rt_oracle.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cfloat>
 #include <cmath>
@@ -210,6 +211,8 @@ inline V3 tri_normal(V3 n0, V3 n1, V3 n2, float u, float v) {
     return normalize((1 - u - v) * n0 + u * n1 + v * n2); // SimplifiedData.cpp:293
 }
 
+static std::atomic<uint64_t> g_leaf_replays{0}; // rays ORA_TRAV_LEAVES resolved by the ordered replay
+
 // =================================================================== flat-array ("sd") scene
 enum : uint32_t { NODE_INTERNAL = 0, NODE_LEAF = 1 }; // SimplifiedData.hpp:30-36
 struct SdNode { // SimplifiedData.hpp:71-77
@@ -367,6 +370,92 @@ struct SdScene {
         intersectRec(node.left, ray, closest, c);
         intersectRec(node.right, ray, closest, c);
     }
+    // ---- the reference's result from its LEAVES alone (checks the argument the product's fast walk rests on) ----
+    // In the reference traversal the interior boxes only prune, and every interior box contains the leaf boxes below
+    // it, so a leaf whose own box passes "(1e-6, closest)" has ancestors that passed: the result is a function of the
+    // leaves.  A leaf is a candidate if the ray meets its box at all (closest = +inf) and the triangle test hits at t;
+    // m = the slab test's entry distance; pos = the leaf's place in the loop's visiting order.  The reference accepts a
+    // candidate iff closest > m and t < closest, in pos order.  If the candidate with the smallest (t, pos) has m <= t
+    // it is the result; otherwise the acceptance rule is replayed over the candidates in pos order.  The leaves are
+    // visited here in REVERSE storage order, to show that the order does not matter.
+    mutable std::vector<uint32_t> leafPos; // node index -> position in IntersectLoop's visiting order (leaves only)
+    void orderLeaves() const {
+        leafPos.assign(nodes.size(), 0xFFFFFFFFu);
+        std::vector<uint32_t> stack{root};
+        uint32_t pos = 0;
+        while (!stack.empty()) {
+            const uint32_t index = stack.back();
+            stack.pop_back();
+            const SdNode &node = nodes[index];
+            if (node.flags == NODE_LEAF) {
+                leafPos[index] = pos++;
+                continue;
+            }
+            pos++;
+            stack.push_back(node.left);
+            stack.push_back(node.right);
+        }
+    }
+    static bool box_entry(V3 pmin, V3 pmax, const Ray &ray, float *entry) { // box_test with (1e-6, +inf), keeping tMin
+        float tMin = 1e-6f, tMax = kInf;
+        for (int a = 0; a < 3; a++) {
+            float invD = ray.inv[a];
+            float t0 = (pmin[a] - ray.o[a]) * invD;
+            float t1 = (pmax[a] - ray.o[a]) * invD;
+            if (invD < 0.0f)
+                std::swap(t0, t1);
+            tMin = t0 > tMin ? t0 : tMin;
+            tMax = t1 < tMax ? t1 : tMax;
+            if (tMax <= tMin)
+                return false;
+        }
+        *entry = tMin;
+        return true;
+    }
+    SdHit intersectLeaves(const Ray &ray, Counters &c, bool *replayed) const {
+        struct Cand {
+            uint32_t pos, node;
+            float t, m;
+        };
+        std::vector<Cand> cands;
+        for (uint32_t index = (uint32_t)nodes.size(); index-- > 0;) {
+            const SdNode &node = nodes[index];
+            if (node.flags != NODE_LEAF || leafPos[index] == 0xFFFFFFFFu)
+                continue;
+            c.box++;
+            float m;
+            if (!box_entry(node.pmin, node.pmax, ray, &m))
+                continue;
+            const SdTri &tri = tris[node.left];
+            c.tri++;
+            TriHit th = tri_test(tri.p[0], tri.p[1], tri.p[2], ray);
+            if (th.hit)
+                cands.push_back(Cand{leafPos[index], index, th.t, m});
+        }
+        const Cand *best = nullptr;
+        for (const Cand &k : cands)
+            if (k.t < kInf && (!best || k.t < best->t || (k.t == best->t && k.pos < best->pos)))
+                best = &k;
+        *replayed = false;
+        if (best && best->m > best->t) { // the winner lies in front of its own leaf box: play the rule in order
+            *replayed = true;
+            std::sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.pos < b.pos; });
+            float closest = kInf;
+            best = nullptr;
+            for (const Cand &k : cands)
+                if (closest > k.m && k.t < closest) {
+                    closest = k.t;
+                    best = &k;
+                }
+        }
+        SdHit h;
+        if (best) {
+            Counters scratch;
+            h = leafHit(nodes[best->node], ray, scratch);
+        }
+        return h;
+    }
+
     // brute force over all triangles in storage order (the "BVH acceleration off" debugging aid)
     SdHit intersectBrute(const Ray &ray, Counters &c) const {
         SdHit closest;
@@ -386,7 +475,12 @@ struct SdScene {
             intersectRec(root, ray, h, c);
         else if (trav == ORA_TRAV_BRUTE)
             h = intersectBrute(ray, c);
-        else
+        else if (trav == ORA_TRAV_LEAVES) {
+            bool replayed = false;
+            h = intersectLeaves(ray, c, &replayed);
+            if (replayed)
+                g_leaf_replays++;
+        } else
             h = intersectLoop(ray, c);
         if (h.hit)
             c.tri_hits++;
@@ -816,8 +910,11 @@ int ora_sd_finalize(void *s) {
     std::vector<uint32_t> idx = sc.sceneIndices;
     sc.root = sc.build(idx.data(), 0, idx.size()); // Program/Scene.cpp:205-206
     sc.sceneIndices = idx;
+    sc.orderLeaves();
     return 0;
 }
+
+uint64_t ora_take_leaf_replays(void) { return g_leaf_replays.exchange(0); }
 void ora_sd_counts(void *s, uint32_t *n_nodes, uint32_t *n_tris, uint32_t *root) {
     SdScene &sc = *(SdScene *)s;
     *n_nodes = (uint32_t)sc.nodes.size();

@@ -33,7 +33,9 @@ typedef struct ora_camera {
 } ora_camera;
 
 enum { ORA_TRIG_LIBM = 0, ORA_TRIG_POLY = 1 };
-enum { ORA_TRAV_LOOP = 0, ORA_TRAV_RECURSIVE = 1, ORA_TRAV_BRUTE = 2 };
+enum { ORA_TRAV_LOOP = 0, ORA_TRAV_RECURSIVE = 1, ORA_TRAV_BRUTE = 2,
+       ORA_TRAV_LEAVES = 3 /* flat scene only: IntersectLoop's result derived from the leaves alone, visited in an
+                              unrelated order (the argument the product's fast walk rests on) */ };
 enum { ORA_ACCUM_RECURSIVE = 0, ORA_ACCUM_FORWARD = 1 };
 
 typedef struct ora_options {
@@ -91,6 +93,8 @@ void ora_sd_flat_tris(void *scene, float *out25);
 void ora_flat_node_unpack(const float *flat9, uint32_t index, void *out36);
 void ora_flat_tri_unpack(const float *flat25, uint32_t index, void *out100);
 void ora_sd_intersect(void *scene, const float *origin, const float *dir, int traversal, ora_hit *out);
+/* Rays ORA_TRAV_LEAVES had to resolve by the ordered replay since the last call of this function. */
+uint64_t ora_take_leaf_replays(void);
 /* Renders samples first_sample .. first_sample+n_samples-1 (1-based sampleCount of
  * Renderer/TracerImpl.cpp:11) as a running mean into image (W*H*4 floats, row 0 = bottom). */
 int ora_sd_render(void *scene, const ora_camera *cam, const ora_options *opt, int width, int height,

@@ -183,3 +183,23 @@ def test_pipelined_device_calls(tracer):
     oimg2, _, _ = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, w, h, 1, 23)
     assert np.array_equal(bits(img.cpu().numpy()), bits(oimg2))
     t.close()
+
+
+def test_camera_a_hair_above_the_surface(tracer):
+    """Camera half a micrometre above a vertex shared by several triangles, looking at it: the primary hits lie
+    between the triangle test's 1e-7 and the slab test's 1e-6 lower bound, in front of their own leaf boxes' entry
+    distance, so the fast walk has to replay the reference's acceptance rule in visiting order for most hitting rays."""
+    tris, _ = objparse.load_obj(WL.DRAGON_2426)
+    ps, os_ = both_scenes([tris])
+    t = tris.reshape(-1, 3, 8)
+    replays = 0
+    for k in (17, 400, 1300):
+        v, n = t[k, 0, 0:3].astype(np.float32), t[k, 0, 3:6].astype(np.float32)
+        n = n / np.linalg.norm(n)
+        pos = (v + n * np.float32(5e-7)).astype(np.float32)
+        cam = R.Camera(1.0, tuple(float(x) for x in pos), 2.0, 16.0 / 9.0, tuple(float(x) for x in v - n))
+        compare(tracer, ps, os_, cam, 64, 36, spp=2, jitter=0.001, min_hits=50)
+        tracer.set_options(bounce_limit=8, seed=3, jitter=0.001, traversal=R.TRAV_FAST)
+        _, _, st = tracer.trace(64, 36, 1, 2)
+        replays += st.replays
+    assert replays > 100
