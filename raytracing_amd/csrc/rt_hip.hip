@@ -99,7 +99,6 @@ struct KParams {
     int bounce_limit;
     uint32_t seed;
     uint32_t sample_offset;
-    int wave_sync;
     uint32_t wave_min_rays;
     // wavefront launches (k_path)
     const float4 *q_in;         // path records of this level (4 x float4 each)
@@ -1692,7 +1691,6 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     if (trav == RT_TRAV_FAST_REFILL)
         trav = RT_TRAV_FAST;
     const int walk = trav == RT_TRAV_WAVE ? WALK_WAVE : (trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY) ? WALK_FAST : WALK_LANE;
-    P.wave_sync = walk == WALK_WAVE ? 1 : 0;
     P.wave_min_rays = o.traversal == RT_TRAV_WAVE ? 0u : 65536u;
     const int variant = (trav == RT_TRAV_NESTED ? 0 : 4) + (old ? 2 : 0) + (st ? 1 : 0);
     const uint32_t full_grid = (uint32_t)ctx->num_cus * (uint32_t)ctx->blocks_per_cu[variant + (variant >= 4 ? 4 * walk : 0)];
