@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <future>
 #include <vector>
 
 namespace fastbvh {
@@ -55,12 +56,14 @@ struct Box {
 
 constexpr int kBins = 32;
 
+constexpr uint32_t kParallelItems = 1u << 15; // ranges below this size are built by one thread
+constexpr int kParallelDepth = 5;              // levels at which a range is shared between two threads
+
 struct Builder {
     const std::vector<Item> &items;
-    std::vector<uint32_t> idx;
-    std::vector<Node> &out;
+    std::vector<uint32_t> idx; // disjoint ranges are permuted in place, so threads never share an element
 
-    Builder(const std::vector<Item> &it, std::vector<Node> &o) : items(it), out(o) {}
+    explicit Builder(const std::vector<Item> &it) : items(it) {}
 
     float centroid2(uint32_t i, int axis) const { return items[i].bmin[axis] + items[i].bmax[axis]; }
 
@@ -139,19 +142,54 @@ struct Builder {
         return s + n / 2; // all centroids coincide: any split is as good as another
     }
 
-    void build(uint32_t s, uint32_t e) {
+    void node_box(Node &nd, uint32_t s, uint32_t e) const {
+        Box b;
+        b.reset();
+        for (uint32_t i = s; i < e; i++)
+            b.grow(items[idx[i]].bmin, items[idx[i]].bmax);
+        for (int k = 0; k < 3; k++) {
+            nd.bmin[k] = b.lo[k];
+            nd.bmax[k] = b.hi[k];
+        }
+    }
+
+    // Orders idx[s, e) so that the smaller part of the split comes first; returns where the larger part starts.
+    uint32_t split_small_first(uint32_t s, uint32_t e) {
+        const uint32_t mid = split(s, e);
+        if (mid - s <= e - mid)
+            return mid;
+        std::rotate(idx.begin() + s, idx.begin() + mid, idx.begin() + e);
+        return s + (e - mid);
+    }
+
+    // Same nodes in the same order as build(), with the two parts of the top `depth` splits built by
+    // different threads into vectors of their own and joined afterwards.
+    void build_shared(uint32_t s, uint32_t e, std::vector<Node> &out, int depth) {
+        if (depth <= 0 || e - s < kParallelItems) {
+            build(s, e, out);
+            return;
+        }
+        const size_t p = out.size();
+        out.emplace_back();
+        node_box(out[p], s, e);
+        out[p].item = 0xFFFFFFFFu;
+        const uint32_t mid = split_small_first(s, e);
+        std::vector<Node> first;
+        auto other = std::async(std::launch::async, [&] { build_shared(s, mid, first, depth - 1); });
+        std::vector<Node> second;
+        build_shared(mid, e, second, depth - 1);
+        other.get();
+        out.insert(out.end(), first.begin(), first.end());
+        out.insert(out.end(), second.begin(), second.end());
+        out[p].size = (uint32_t)(out.size() - p);
+    }
+
+    void build(uint32_t s, uint32_t e, std::vector<Node> &out) {
         std::vector<uint32_t> spine; // nodes whose subtree ends where this call's range ends
         for (;;) {
             const uint32_t p = (uint32_t)out.size();
             out.emplace_back();
-            Box b;
-            b.reset();
-            for (uint32_t i = s; i < e; i++)
-                b.grow(items[idx[i]].bmin, items[idx[i]].bmax);
-            for (int k = 0; k < 3; k++) {
-                out[p].bmin[k] = b.lo[k];
-                out[p].bmax[k] = b.hi[k];
-            }
+            node_box(out[p], s, e);
             out[p].item = 0xFFFFFFFFu;
             out[p].size = 1;
             if (e - s == 1) {
@@ -164,18 +202,11 @@ struct Builder {
                 break;
             }
             spine.push_back(p);
-            const uint32_t mid = split(s, e);
             // The smaller part is emitted first through recursion (its size at least halves every time, so the
             // recursion depth stays logarithmic however lopsided the splits are); the larger part continues here.
-            if (mid - s <= e - mid) {
-                build(s, mid);
-                s = mid;
-            } else {
-                std::rotate(idx.begin() + s, idx.begin() + mid, idx.begin() + e);
-                const uint32_t small = e - mid;
-                build(s, s + small);
-                s = s + small;
-            }
+            const uint32_t mid = split_small_first(s, e);
+            build(s, mid, out);
+            s = mid;
         }
         const uint32_t end = (uint32_t)out.size();
         for (uint32_t p : spine)
@@ -190,11 +221,14 @@ struct Builder {
 inline void build(const std::vector<Item> &items, std::vector<Node> &out) {
     if (items.empty())
         return;
-    detail::Builder b(items, out);
+    detail::Builder b(items);
     b.idx.resize(items.size());
     for (uint32_t i = 0; i < (uint32_t)items.size(); i++)
         b.idx[i] = i;
-    b.build(0, (uint32_t)items.size());
+    if (items.size() < detail::kParallelItems)
+        b.build(0, (uint32_t)items.size(), out);
+    else
+        b.build_shared(0, (uint32_t)items.size(), out, detail::kParallelDepth);
 }
 
 } // namespace fastbvh

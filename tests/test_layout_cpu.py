@@ -8,7 +8,9 @@ The reference-order array must be the reference's own tree in its own visiting o
 """
 import numpy as np
 
-from helpers import R, WL, objparse
+import os
+
+from helpers import R, ROOT, WL, objparse
 
 KIND_INTERNAL, KIND_TRI, KIND_MESH, KIND_SPHERE = 0, 1, 2, 4
 
@@ -171,3 +173,14 @@ def test_layout_rejects_bad_trees():
     rc = R._native.hip().rt_layout_scene(nodes.ctypes.data, len(nodes), sc.root, sc.tris().ctypes.data, len(sc.tris()),
                                          None, 0, None, 0, 0, C.byref(v))
     assert rc == -5
+
+
+def test_fast_tree_is_the_same_whether_one_thread_or_many_build_it(tmp_path):
+    """Large scenes share the top splits of the fast-tree build between threads; the nodes must not depend on it."""
+    import subprocess
+    exe = str(tmp_path / "fast_bvh_check")
+    src = os.path.join(ROOT, "tests", "native", "fast_bvh_check.cpp")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", src, "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok ") == 8
