@@ -787,6 +787,9 @@ RT_D void fast_walk_from(const KParams &P, const f3 o, const f3 d, const f3 inv,
             if (STATS)
                 cnt.tri++;
             const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
+            // All nine floats of the triangle are fetched before the test starts: left alone, the compiler sinks the
+            // load of p0 behind the determinant test, which puts a second memory round trip into most triangle tests.
+            asm volatile("" : : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w), "v"(q2.x));
             const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
             const float EPSILON = 1e-7f;
             f3 h = cross3(d, e2);
