@@ -142,6 +142,8 @@ def host():
         for name in ("rth_harness_load", "rth_harness_render", "rth_harness_reset", "rth_harness_sample_count"):
             getattr(L, name).argtypes = [vp]
         L.rth_harness_resize.argtypes = [vp, C.c_int, C.c_int]
+        L.rth_set_bvh_accel.argtypes = [C.c_int]
+        L.rth_set_bvh_accel.restype = None
         L.rth_harness_set_camera_position.argtypes = [vp, fp]
         L.rth_harness_set_camera_position.restype = None
         L.rth_harness_output.argtypes = [vp, fp, up, up]

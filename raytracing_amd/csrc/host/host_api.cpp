@@ -21,6 +21,9 @@ std::shared_mutex OldSceneMutex;
 namespace Trace {
 int bounceLimit = 4;
 }
+namespace BVHSettings {
+bool toggleBVHAccel = true;
+}
 } // namespace rthost
 
 using namespace rthost;
@@ -196,6 +199,7 @@ int rth_harness_resize(void *h, int w, int hgt) { // Renderer::resize, Renderer.
         ((Harness *)h)->tracer->resetSamples();
     });
 }
+void rth_set_bvh_accel(int on) { BVHSettings::toggleBVHAccel = on != 0; }
 void rth_harness_set_camera_position(void *h, const float *pos3) { std::memcpy(((Harness *)h)->cam.position, pos3, 12); }
 int rth_harness_sample_count(void *h) { return ((Harness *)h)->tracer->sampleCount(); }
 int rth_harness_output(void *h, float *out, uint32_t *w, uint32_t *hgt) {

@@ -88,6 +88,9 @@ extern std::shared_mutex OldSceneMutex;
 namespace Trace {
 extern int bounceLimit; // CPURayTrace/Trace.hpp:16
 }
+namespace BVHSettings {
+extern bool toggleBVHAccel; // Program/BVHUI.hpp:14: the "BVH Acceleration" checkbox; read by the old-scene path only
+}                           // (Trace.cpp:42-45, Mesh.hpp:156), as in the reference
 
 // ---- the plug-in interface, as in Renderer/RenderInterfaces.hpp ---------------------------------
 class ITraceMethod {
@@ -236,6 +239,7 @@ template <int ESTIMATOR, class Context> class TraceHIPImpl : public ITraceMethod
         opt.jitter = DIContext.perturbStrength;
         opt.tile_rank = 0;
         opt.tile_world = 1;
+        opt.traversal = (ESTIMATOR == RT_EST_OLD_RECURSIVE && !BVHSettings::toggleBVHAccel) ? RT_TRAV_BRUTE : RT_TRAV_AUTO;
         DIContext.check(rt_set_options(DIContext.ctx, &opt), "rt_set_options");
         staging.resize((size_t)traceInput.Width * traceInput.Height * 4);
         DIContext.check(rt_trace(DIContext.ctx, (int)traceInput.Width, (int)traceInput.Height, sampleCount, 1,

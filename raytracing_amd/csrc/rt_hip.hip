@@ -287,6 +287,95 @@ RT_D void closest_hit(const KParams &P, const f3 o, const f3 d, const f3 inv, Be
     }
 }
 
+// "BVH acceleration" switched off (BVHSettings::toggleBVHAccel, Program/BVHUI.hpp:14): every primitive is tested, no
+// box is.  Old scene: Scene::intersectClosest (Program/Scene.hpp:83-95) takes the objects in the order Scene::update
+// left them in -- BVH::build sorts that very vector (BVH.hpp:116-119, :54-65), so it is the left-to-right order of the
+// scene-level leaves, which is the order of the records here -- and accepts "t < closest.t"; a mesh without its inner
+// BVH (Mesh::intersect, Mesh.hpp:161-172) takes its triangles in storage order, which the strict comparison turns into
+// the smallest (t, triangle index).  The flat scene has no such switch in the reference; it is given the same meaning:
+// all triangles in storage order.
+template <bool OLD, bool STATS>
+RT_D void closest_hit_brute(const KParams &P, const f3 o, const f3 d, Best &best, Cnt &cnt) {
+    best = Best{__builtin_inff(), 0.0f, 0.0f, kNone};
+    uint32_t bidx = kNone;      // storage index of the triangle `best` holds
+    Best outer = best;          // OLD: the scene-level closest while inside a mesh
+    uint32_t inner_end = kNone; // OLD: first record after the current mesh's triangles
+    const uint32_t n = P.n_nodes * 32u;
+    for (uint32_t idx = 0; idx < n; idx += 32u) {
+        if (OLD) {
+            if (idx == inner_end) {
+                if (!(best.t < outer.t))
+                    best = outer;
+                inner_end = kNone;
+                bidx = kNone;
+            }
+        }
+        const float4 b = ((const float4 *)((const char *)P.nodes + idx))[1];
+        const uint32_t kind = __float_as_uint(b.w);
+        const uint32_t k = kind & 7u;
+        const uint32_t slot = kind >> 3;
+        if (k == KIND_TRI) {
+            if (STATS)
+                cnt.tri++;
+            const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
+            const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+            const float EPSILON = 1e-7f;
+            f3 h = cross3(d, e2);
+            float det = dot3(e1, h);
+            if (!(det > -EPSILON && det < EPSILON)) {
+                float f = 1.0f / det;
+                f3 s = o - p0;
+                float u = f * dot3(s, h);
+                if (!(u < 0.0f || u > 1.0f)) {
+                    f3 q = cross3(s, e1);
+                    float v = f * dot3(d, q);
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        float t = f * dot3(e2, q);
+                        const uint32_t ti = __float_as_uint(q2.y);
+                        const bool in_order_group = !OLD || inner_end != kNone; // triangles scanned in storage order
+                        if (t > EPSILON && (t < best.t || (in_order_group && t == best.t && t < __builtin_inff() && ti < bidx))) {
+                            best = Best{t, u, v, slot};
+                            bidx = ti;
+                        }
+                    }
+                }
+            }
+        } else if (OLD && k == KIND_SPHERE) { // Sphere::intersect, Objects.hpp:43-72
+            if (STATS)
+                cnt.sph++;
+            const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
+            f3 oc = mk3(s0.x, s0.y, s0.z) - o;
+            float qa = dot3(d, d);
+            float qb = -2.0f * dot3(d, oc);
+            float qc = dot3(oc, oc) - s0.w * s0.w;
+            float disc = qb * qb - 4 * qa * qc;
+            if (!(disc < 0)) {
+                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
+                bool ok = !(t < 0);
+                if (!ok && __float_as_uint(s1.z) != 0u) {
+                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
+                    ok = !(t < 0);
+                }
+                if (ok && t < best.t) {
+                    best = Best{t, 0.0f, 0.0f, kSphereBit | slot};
+                    bidx = kNone;
+                }
+            }
+        } else if (OLD && k == KIND_MESH) { // Mesh::intersect starts a fresh closest hit (Mesh.hpp:154-160)
+            outer = best;
+            inner_end = __float_as_uint(b.z);
+            best = Best{__builtin_inff(), 0.0f, 0.0f, kNone};
+            bidx = kNone;
+        }
+    }
+    if (OLD) {
+        if (inner_end != kNone) {
+            if (!(best.t < outer.t))
+                best = outer;
+        }
+    }
+}
+
 struct RayState {
     f3 o, d, inv;
 };
@@ -1109,7 +1198,7 @@ RT_D bool camera_path(const KParams &P, const uint32_t item, Path &path, uint32_
 // full waves, and no lane ever waits for a neighbour's longer path.  The per-sample colours are folded
 // into the running mean afterwards, in sample order, by k_fold, which reproduces the reference's
 // "pixel = (pixel*(n-1) + new)/n" (Renderer/TraceMethods.cpp:59) bit for bit.
-constexpr int WALK_LANE = 0, WALK_WAVE = 1, WALK_FAST = 2;
+constexpr int WALK_LANE = 0, WALK_WAVE = 1, WALK_FAST = 2, WALK_BRUTE = 3;
 template <bool OLD, bool STATS, int WALK>
 __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1224,6 +1313,8 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
             if (live) {
                 if (WALK == WALK_FAST)
                     closest_hit_fast<OLD, STATS>(P, path.o, path.d, path.inv, hit, cnt);
+                else if (WALK == WALK_BRUTE)
+                    closest_hit_brute<OLD, STATS>(P, path.o, path.d, hit, cnt);
                 else
                     closest_hit<OLD, STATS>(P, path.o, path.d, path.inv, hit, cnt);
             }
@@ -1693,10 +1784,12 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     const bool refill = trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && ctx->scene_bytes > kRefillSceneBytes);
     if (trav == RT_TRAV_FAST_REFILL)
         trav = RT_TRAV_FAST;
-    const int walk = trav == RT_TRAV_WAVE ? WALK_WAVE : (trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY) ? WALK_FAST : WALK_LANE;
+    const int walk = trav == RT_TRAV_WAVE ? WALK_WAVE : (trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY) ? WALK_FAST
+                     : trav == RT_TRAV_BRUTE                                                               ? WALK_BRUTE
+                                                                                                           : WALK_LANE;
     P.wave_min_rays = o.traversal == RT_TRAV_WAVE ? 0u : 65536u;
     const int variant = (trav == RT_TRAV_NESTED ? 0 : 4) + (old ? 2 : 0) + (st ? 1 : 0);
-    const uint32_t full_grid = (uint32_t)ctx->num_cus * (uint32_t)ctx->blocks_per_cu[variant + (variant >= 4 ? 4 * walk : 0)];
+    const uint32_t full_grid = (uint32_t)ctx->num_cus * (uint32_t)ctx->blocks_per_cu[variant + (variant >= 4 ? 4 * (walk == WALK_BRUTE ? WALK_LANE : walk) : 0)];
     if (ctx->pending == ctx->events.size()) {
         hipEvent_t a, b;
         RT_HIP_CHECK(ctx, hipEventCreate(&a));
@@ -1792,6 +1885,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, 0, pp.stream, P);     \
         else if (walk == WALK_FAST && refill) hipLaunchKernelGGL((k_refill<OLD_, STATS_>), grid, block, 0, pp.stream, P); \
         else if (walk == WALK_FAST) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_FAST>), grid, block, 0, pp.stream, P); \
+        else if (walk == WALK_BRUTE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_BRUTE>), grid, block, 0, pp.stream, P); \
         else hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_LANE>), grid, block, 0, pp.stream, P);                       \
     } while (0)
             switch (variant) {
@@ -2266,7 +2360,7 @@ int rt_set_options(rt_ctx *ctx, const rt_options *opt) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (opt->bounce_limit < 0 || opt->bounce_limit > kMaxLevels - 2 || opt->tile_world < 1 || opt->tile_rank < 0 || opt->tile_rank >= opt->tile_world ||
         (opt->estimator != RT_EST_SD_LOOP && opt->estimator != RT_EST_OLD_RECURSIVE) || opt->traversal < 0 ||
-        opt->traversal > RT_TRAV_FAST_REFILL)
+        opt->traversal > RT_TRAV_BRUTE)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad options");
     ctx->opt = *opt;
     return RT_OK;

@@ -6,7 +6,7 @@ import numpy as np
 from . import _native as N
 
 EST_SD_LOOP, EST_OLD_RECURSIVE = 0, 1
-TRAV_AUTO, TRAV_LANE, TRAV_WAVE, TRAV_NESTED, TRAV_FAST, TRAV_FAST_REPLAY, TRAV_REFERENCE, TRAV_FAST_REFILL = 0, 1, 2, 3, 4, 5, 6, 7
+TRAV_AUTO, TRAV_LANE, TRAV_WAVE, TRAV_NESTED, TRAV_FAST, TRAV_FAST_REPLAY, TRAV_REFERENCE, TRAV_FAST_REFILL, TRAV_BRUTE = 0, 1, 2, 3, 4, 5, 6, 7, 8
 MISS = 0xFFFFFFFF
 
 _STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_HIP", -4: "RT_ERR_NO_SCENE",
@@ -169,6 +169,12 @@ class PluginHarness:
     def set_camera_position(self, pos):
         p = np.ascontiguousarray(pos, dtype=np.float32)
         N.host().rth_harness_set_camera_position(self._h, p.ctypes.data_as(C.POINTER(C.c_float)))
+
+    @staticmethod
+    def set_bvh_accel(on):
+        """BVHSettings::toggleBVHAccel (Program/BVHUI.hpp:14), a process-wide switch as in the reference; the UI sets
+        RenderState::Dirty with it (BVHUI.hpp:25), i.e. the caller resets the samples."""
+        N.host().rth_set_bvh_accel(1 if on else 0)
 
     def sample_count(self):
         return N.host().rth_harness_sample_count(self._h)

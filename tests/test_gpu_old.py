@@ -38,6 +38,16 @@ def _compare(tracer, ps, os_, cam, w, h, spp, bounce, seed, jitter=0.001):
             assert (st.box_tests, st.tri_tests, st.sph_tests) == (ost.box_tests, ost.tri_tests, ost.sph_tests), trav
         assert np.array_equal(bits(img), bits(oimg)), trav
         REPLAYS[trav] = REPLAYS.get(trav, 0) + st.replays
+    # "BVH Acceleration" unticked (BVHUI.hpp:14): Scene::intersectClosest + Mesh::intersect without the inner BVH
+    opt.traversal = O.TRAV_BRUTE
+    bimg, bprim, bst = os_.render(oracle_camera(cam), opt, w, h, 1, spp, want_primary=True)
+    opt.traversal = O.TRAV_LOOP
+    tracer.set_options(bounce_limit=bounce, estimator=R.EST_OLD_RECURSIVE, seed=seed, jitter=jitter, collect_stats=True,
+                       traversal=R.TRAV_BRUTE)
+    gimg, gprim, gst = tracer.trace(w, h, 1, spp, want_primary=True)
+    assert np.count_nonzero(gprim != bprim) == 0
+    assert (gst.rays, gst.box_tests, gst.tri_tests, gst.sph_tests) == (bst.rays, 0, bst.tri_tests, bst.sph_tests)
+    assert np.array_equal(bits(gimg), bits(bimg))
     return img, opt
 
 
@@ -148,6 +158,16 @@ def test_plugin_adaptors_drive_the_tracer(tracer):
     h.render()
     oimg1, _, _ = os_.render(oracle_camera(cam), opt, 160, 90, 1, 1)
     assert np.array_equal(bits(h.output()), bits(oimg1))
+    # the "BVH Acceleration" checkbox (BVHUI.hpp:14,25): unticked, the same frame comes from the brute-force scan
+    try:
+        h.set_bvh_accel(False)
+        h.reset()
+        h.render()
+        opt.traversal = O.TRAV_BRUTE
+        bimg, _, _ = os_.render(oracle_camera(cam), opt, 160, 90, 1, 1)
+        assert np.array_equal(bits(h.output()), bits(bimg))
+    finally:
+        h.set_bvh_accel(True)
     # resize
     h.resize(96, 54)
     h.render()

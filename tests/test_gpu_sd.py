@@ -57,6 +57,27 @@ def test_primary_ids_dragon2426_400x225(tracer, dragon2426, trav):
     assert np.array_equal(bits(img), bits(oimg))
 
 
+def test_bvh_acceleration_off(tracer, dragon2426):
+    """RT_TRAV_BRUTE = every triangle, no box (the reference's "BVH Acceleration" debugging switch, BVHUI.hpp:14, given to
+    the flat scene as well): same hits as the oracle's brute-force scan, and -- the reference's own check for its BVH,
+    closest-hit t must agree -- the same image as the tree walk except where two triangles tie."""
+    ps, os_ = dragon2426
+    tracer.upload(ps)
+    tracer.set_camera(WL.DRAGON_2426_CAMERA)
+    tracer.set_options(bounce_limit=3, seed=7, collect_stats=True, traversal=R.TRAV_BRUTE)
+    img, prim, st = tracer.trace(160, 90, 1, 2, want_primary=True)
+    opt = O.make_options(bounce_limit=3, seed=7, trig=O.TRIG_POLY, traversal=O.TRAV_BRUTE)
+    oimg, oprim, ost = os_.render(oracle_camera(WL.DRAGON_2426_CAMERA), opt, 160, 90, 1, 2, want_primary=True)
+    assert (prim != R.MISS).sum() > 200
+    assert np.count_nonzero(prim != oprim) == 0
+    assert (st.rays, st.box_tests, st.tri_tests, st.tri_hits) == (ost.rays, 0, ost.tri_tests, ost.tri_hits)
+    assert st.tri_tests == st.rays * 2426
+    assert np.array_equal(bits(img), bits(oimg))
+    tracer.set_options(bounce_limit=3, seed=7, traversal=R.TRAV_FAST)
+    timg, tprim, _ = tracer.trace(160, 90, 1, 2, want_primary=True)
+    assert np.count_nonzero(tprim != prim) <= 2 and np.mean(bits(timg) != bits(img)) < 1e-3
+
+
 def test_primary_ids_dragon2426_1080p(tracer, dragon2426):
     ps, os_ = dragon2426
     tracer.upload(ps)
