@@ -172,3 +172,49 @@ def test_image_writer_gamma_and_row_order(tmp_path):
     idat = data[data.index(b"IDAT") + 4:data.index(b"IEND") - 8]
     rows = zlib.decompress(idat)
     assert rows == b"".join(b"\x00" + px[y].tobytes() for y in range(2))
+
+
+def test_flat_float_dump_matches_the_reference_stream_format():
+    """SimplifiedData::DumpFlatFloatDataString (Program/Utils.cpp:33-50): default stream formatting, 'f' suffix, setw(12)
+    on whatever is written next, a line break after every 40th value.  The first values are those of the reference's own
+    dump (GLSL/GPURayTrace/testScene.glsl:5: "0f,           0f,          -1f,      -1e-06f,    -1.55671f, ...")."""
+    from raytracing_amd import bvhdebug
+    one = np.array([1], dtype=np.uint32).view(np.float32)[0]
+    vals = np.array([0.0, 0.0, -1.0, -1e-6, -1.55671, 1.0, 1.38598, -0.996302, one], dtype=np.float32)
+    assert bvhdebug.dump_flat_floats(vals) == ("0f,           0f,          -1f,      -1e-06f,    -1.55671f,           1f,"
+                                               "     1.38598f,   -0.996302f,  1.4013e-45f")
+    text = bvhdebug.dump_flat_floats(np.arange(41, dtype=np.float32))
+    lines = text.split("\n")
+    assert len(lines) == 2 and lines[0].endswith("39f," + " " * 11) and lines[1] == "40f"
+    # the product's own flat arrays go through it unchanged: 9 floats per node, 25 per triangle
+    sc = product_sd_scene([WL.CYLINDER])
+    fn, ft = sc.flat()
+    assert bvhdebug.dump_flat_floats(fn).count("f") >= fn.size and fn.size == 9 * len(sc.nodes()) and ft.size == 25 * len(sc.tris())
+
+
+def test_bvh_wireframe_boxes_follow_the_reference_visualiser(tmp_path):
+    """BVHSettings::RenderVisualization (Program/BVHUI.hpp:30-103): which boxes are drawn for a depth window."""
+    from raytracing_amd import bvhdebug
+    sc = product_sd_scene([WL.DRAGON_2426])
+    nodes = sc.nodes()
+    everything = bvhdebug.wireframe_boxes(sc, 0, 1 << 30, show_leaf=True)
+    assert len(everything) == len(nodes) == 4851 and sum(b[3] for b in everything) == 2426
+    assert len(bvhdebug.wireframe_boxes(sc, 0, 1 << 30)) == 2425                     # leaves only with "Show Leaf AABB"
+    # the flat tree's "depth" is the height of the traversal stack (BVHUI.hpp:70): 1 for the root -- and again for every
+    # node on the root's left spine, each popped when nothing else is stacked
+    top = bvhdebug.wireframe_boxes(sc, 1, 1)
+    spine, i = [], sc.root
+    while int(nodes[i]["flags"]) == 0:
+        spine.append(i)
+        i = int(nodes[i]["left"])
+    assert len(top) == len(spine) and all(np.array_equal(b[0], nodes[j]["pmin"]) for b, j in zip(top, spine))
+    assert bvhdebug.wireframe_boxes(sc, 0, 0) == []
+    n = bvhdebug.write_wireframe_obj(str(tmp_path / "b.obj"), bvhdebug.wireframe_boxes(sc, 1, 3))
+    text = (tmp_path / "b.obj").read_text()
+    assert text.count("\nv ") == 8 * n and text.count("\nl ") == 12 * n and "g depth_2" in text
+    # pointer tree: depth from 0, object boxes always drawn, meshes not descended into
+    tris, _ = objparse.load_obj(WL.CYLINDER)
+    old = product_old_scene(WL.small_sphere_scene(), [(tris, R.MAT_LAMBERTIAN, (0.8, 0.3, 0.3, 1.0), 0.0)])
+    boxes = bvhdebug.wireframe_boxes(old, 0, 40)
+    assert sum(b[3] for b in boxes) == 6 and sum(not b[3] for b in boxes) == 5
+    assert [b[2] for b in boxes if not b[3]][0] == 0
