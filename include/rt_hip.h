@@ -231,6 +231,12 @@ int rt_layout_scene(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const
                     rt_layout_view *out);
 void rt_layout_free(rt_layout_view *view);
 
+/* Page-locked host memory for the buffers handed to rt_trace: the copy of the W*H*4 float mean that stands in for
+ * Texture2D::setData's upload (GLShader/Texture.cpp:86-91) then runs at PCIe rate instead of through a pageable
+ * bounce buffer.  rt_alloc_host returns NULL on failure; any host pointer works with rt_trace, these are only faster. */
+void *rt_alloc_host(uint64_t bytes);
+void rt_free_host(void *ptr);
+
 /* Library self-description: "rt_hip <version> gfx950". */
 const char *rt_version(void);
 

@@ -59,7 +59,7 @@ assert C.sizeof(Node) == 36 and C.sizeof(Tri) == 100 and C.sizeof(Sphere) == 24 
 # every symbol include/rt_hip.h declares
 HIP_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_set_options",
                "rt_reset", "rt_trace", "rt_trace_device", "rt_set_stream", "rt_sync", "rt_version", "rt_layout_scene",
-               "rt_layout_free", "rt_set_pipelining", "rt_join"]
+               "rt_layout_free", "rt_set_pipelining", "rt_join", "rt_alloc_host", "rt_free_host"]
 
 _hip = None
 _host = None
@@ -90,6 +90,10 @@ def hip():
         L.rt_set_pipelining.argtypes = [vp, C.c_int]
         L.rt_join.argtypes = [vp]
         L.rt_version.restype = C.c_char_p
+        L.rt_alloc_host.argtypes = [C.c_uint64]
+        L.rt_alloc_host.restype = C.c_void_p
+        L.rt_free_host.argtypes = [C.c_void_p]
+        L.rt_free_host.restype = None
         L.rt_layout_scene.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, C.c_int,
                                       C.POINTER(LayoutViewC)]
         L.rt_layout_free.argtypes = [C.POINTER(LayoutViewC)]

@@ -215,11 +215,25 @@ class LoadSceneHIP : public ILoadMethod {
 // calls; sampleCount == 1 restarts it.
 template <int ESTIMATOR, class Context> class TraceHIPImpl : public ITraceMethod {
     Context &DIContext;
-    std::vector<float> staging;
+    // page-locked staging for the image on its way to Texture2D::setData (pageable memory if that cannot be had)
+    float *staging = nullptr;
+    size_t stagingFloats = 0;
+    bool stagingPinned = false;
+    void releaseStaging() {
+        if (staging && stagingPinned)
+            rt_free_host(staging);
+        else
+            delete[] staging;
+        staging = nullptr;
+        stagingFloats = 0;
+    }
 
   public:
     rt_stats lastStats{};
     explicit TraceHIPImpl(Context &c) : DIContext(c) {}
+    ~TraceHIPImpl() override { releaseStaging(); }
+    TraceHIPImpl(const TraceHIPImpl &) = delete;
+    TraceHIPImpl &operator=(const TraceHIPImpl &) = delete;
     void trace(const Texture2D &traceInput, Texture2D &traceOutput, int sampleCount) override {
         const Camera &c = DIContext.cam; // read live every call, the UI may have moved it
         rt_camera cam;
@@ -241,11 +255,19 @@ template <int ESTIMATOR, class Context> class TraceHIPImpl : public ITraceMethod
         opt.tile_world = 1;
         opt.traversal = (ESTIMATOR == RT_EST_OLD_RECURSIVE && !BVHSettings::toggleBVHAccel) ? RT_TRAV_BRUTE : RT_TRAV_AUTO;
         DIContext.check(rt_set_options(DIContext.ctx, &opt), "rt_set_options");
-        staging.resize((size_t)traceInput.Width * traceInput.Height * 4);
-        DIContext.check(rt_trace(DIContext.ctx, (int)traceInput.Width, (int)traceInput.Height, sampleCount, 1,
-                                 staging.data(), nullptr, &lastStats),
+        const size_t need = (size_t)traceInput.Width * traceInput.Height * 4;
+        if (need != stagingFloats) {
+            releaseStaging();
+            staging = (float *)rt_alloc_host(need * sizeof(float));
+            stagingPinned = staging != nullptr;
+            if (!staging)
+                staging = new float[need];
+            stagingFloats = need;
+        }
+        DIContext.check(rt_trace(DIContext.ctx, (int)traceInput.Width, (int)traceInput.Height, sampleCount, 1, staging,
+                                 nullptr, &lastStats),
                         "rt_trace"); // RT_ERR_NO_SCENE carries "Scene is not loaded." (TraceMethods.cpp:54-56)
-        traceOutput.setData(staging.data());
+        traceOutput.setData(staging);
     }
 };
 using TraceSdSceneHIP = TraceHIPImpl<RT_EST_SD_LOOP, SdSceneHIPContext>;

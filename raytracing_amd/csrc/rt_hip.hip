@@ -2221,6 +2221,17 @@ int build_layout(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt
 
 extern "C" {
 
+void *rt_alloc_host(uint64_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess)
+        return nullptr;
+    return p;
+}
+void rt_free_host(void *ptr) {
+    if (ptr)
+        (void)hipHostFree(ptr);
+}
+
 const char *rt_version(void) { return "rt_hip 0.1 gfx950"; }
 
 int rt_create(rt_ctx **out, int device) {
