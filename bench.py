@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dragon18520_1080p")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (0 = the workload's)")
+    ap.add_argument("--split", choices=("sample", "tile"), default="sample",
+                    help="N > 1: sample = every rank renders its own samples of the whole frame (weak scaling, the default); "
+                         "tile = the ranks share the tiles of one frame (strong scaling)")
     ap.add_argument("--traversal", type=int, default=4, help="RT_TRAV_* of the timed steps (4 = fast walk, 7 = with lane re-fill)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-counts", action="store_true",
@@ -116,10 +119,16 @@ def main():
     tr.set_stream(torch.cuda.current_stream().cuda_stream)
     img = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
 
+    tile_split = args.split == "tile" and world > 1
+
     def options(stats, traversal=args.traversal):
-        tr.set_options(bounce_limit=wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
-                       collect_stats=stats, sample_offset=P.sample_offset(rank, spp * max(args.steps, args.warmup)),
-                       traversal=traversal)
+        if tile_split:  # the same samples on every rank, disjoint 8x8 tiles (tile k belongs to rank k % world)
+            tr.set_options(bounce_limit=wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
+                           collect_stats=stats, tile_rank=rank, tile_world=world, traversal=traversal)
+        else:
+            tr.set_options(bounce_limit=wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
+                           collect_stats=stats, sample_offset=P.sample_offset(rank, spp * max(args.steps, args.warmup)),
+                           traversal=traversal)
 
     # One render = `n` steps of `spp` samples accumulated into the running mean on the device (the reference's
     # progressive sampleCount protocol, Renderer/TracerImpl.cpp:9-12), then -- N > 1 -- ONE RCCL reduce(SUM) of the
@@ -132,7 +141,10 @@ def main():
         for i in range(n):
             tr.trace_device(W, H, 1 + i * spp, spp, img.data_ptr())
         tr.join()
-        P.combine_sample_split(img, dst=0)
+        if tile_split:  # pixels of other ranks are zero here: one reduce(SUM) assembles the frame exactly
+            P.combine_tile_split(img, dst=0)
+        else:
+            P.combine_sample_split(img, dst=0)
 
     # work of one trace call: counted once, untimed, by the counting variant of the same kernel
     options(True)
@@ -187,7 +199,7 @@ def main():
             return 27 * c.box_tests + 56 * c.tri_tests + 24 * c.sph_tests + 60 * c.rays
 
         # per pixel sample: one 16 B colour written and read once (the fold); per pixel: the 16 B mean written
-        image_bytes = 32 * W * H * spp + 16 * W * H
+        image_bytes = (32 * W * H * spp + 16 * W * H) // (world if tile_split else 1)
         alg_bytes = traversal_bytes(counts) + image_bytes
         alg_ops = traversal_ops(counts)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -199,18 +211,22 @@ def main():
         out = {
             "metric": "Mrays/s (all bounces)", "value": rays_total / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if tile_split else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "Stanford Dragon mesh bundled with the reference (data/models), no external data"
                     if wl.estimator == R.EST_SD_LOOP else "synthetic",
             "config": {"workload": wl.name, "width": W, "height": H, "spp_per_step_per_gpu": spp,
                        "bounce_limit": wl.bounce_limit, "rays_per_step_per_gpu": int(st.rays // args.steps),
                        "traversal": "fast walk (own hierarchy over the reference's leaf boxes; hits bit-identical "
                                     "to the reference-order walk)",
-                       "parallelism": "scene replicated, sample-index range per GPU, steps accumulate on the device, one RCCL reduce of the W*H*4 float mean at the end of the render"
-                                      if world > 1 else "single GPU"},
+                       "parallelism": "single GPU" if world == 1 else
+                                      "scene replicated, interleaved 8x8 image tiles per GPU (tile k -> GPU k % N), steps accumulate on "
+                                      "the device, one RCCL reduce of the zero-padded W*H*4 float image at the end of the render"
+                                      if tile_split else
+                                      "scene replicated, sample-index range per GPU, steps accumulate on the device, one RCCL "
+                                      "reduce of the W*H*4 float mean at the end of the render"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_path (one launch per bounce level) + k_fold = one trace call",
+                         "kernel": "k_path (k_refill for scenes larger than the L2s), one launch per bounce level, + k_fold = one trace call",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(alg_bytes),
                          "note": "algorithmic bytes = the tests this walk performs x their record payload + the "
                                  "per-sample colour traffic; node and triangle records are L2-resident for this "
