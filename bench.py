@@ -68,8 +68,8 @@ def cpu_baseline(wl, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dragon18520_1080p")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (0 = the workload's)")
     ap.add_argument("--split", choices=("sample", "tile"), default="sample",
