@@ -40,6 +40,7 @@
 
 #include "rt_hip.h"
 #include "fast_bvh.hpp"
+#include "fastdiv.hpp"
 
 #define RT_HD __host__ __device__ __forceinline__
 #define RT_D __device__ __forceinline__
@@ -94,6 +95,8 @@ struct KParams {
     int force_replay; // fast walk: resolve every ray by the ordered replay (verification aid)
     uint32_t n_my_tiles;
     int W, H, tiles_x;
+    FastDiv div_tiles_x, div_per_tile; // exact division by tiles_x and by 64 * S (camera_path)
+    uint32_t seed_hash;                // pcg(seed): the part of the per-pixel RNG key that does not depend on the pixel
     int tile_rank, tile_world;
     int first_sample, n_samples;
     int bounce_limit;
@@ -117,7 +120,7 @@ struct KParams {
 };
 
 // ------------------------------------------------------------------ counter RNG
-RT_D uint32_t pcg(uint32_t v) {
+RT_HD uint32_t pcg(uint32_t v) {
     uint32_t s = v * 747796405u + 2891336453u;
     uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
     return (w >> 22u) ^ w;
@@ -1151,12 +1154,13 @@ RT_D bool shade_path(const KParams &P, Path &path, const Best &hit, const uint32
 template <bool OLD>
 RT_D bool camera_path(const KParams &P, const uint32_t item, Path &path, uint32_t &cidx) {
     const uint32_t per_tile = 64u * (uint32_t)P.S;
-    const uint32_t j = item / per_tile;
+    const uint32_t j = fastdiv(item, P.div_per_tile);
     const uint32_t s = (item - j * per_tile) >> 6;
     const uint32_t in_tile = item & 63u;
     const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
-    const int x = (int)(tile % (uint32_t)P.tiles_x) * 8 + (int)(in_tile & 7u);
-    const int y = (int)(tile / (uint32_t)P.tiles_x) * 8 + (int)(in_tile >> 3);
+    const uint32_t tile_y = fastdiv(tile, P.div_tiles_x);
+    const int x = (int)(tile - tile_y * (uint32_t)P.tiles_x) * 8 + (int)(in_tile & 7u);
+    const int y = (int)tile_y * 8 + (int)(in_tile >> 3);
     bool live = item < P.n_items && x < P.W && y < P.H;
     const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
     const int n = P.chunk_first + (int)s;
@@ -1166,7 +1170,7 @@ RT_D bool camera_path(const KParams &P, const uint32_t item, Path &path, uint32_
     f3 view = normalize3(mk3(u * P.cam_w - P.cam_w / 2, v * P.cam_h - P.cam_h / 2, P.focal));
     view.x = -view.x;
     const f3 dir0 = basis_mul(P.bx, P.by, P.bz, view);
-    path.key = pcg(pcg(pcg(P.seed) + pixel) + (uint32_t)n + P.sample_offset);
+    path.key = pcg(pcg(P.seed_hash + pixel) + (uint32_t)n + P.sample_offset);
     // glm::linearRand(vec3(-s), vec3(s)), Include/Random.hpp:13-16
     const float js = P.jitter;
     f3 jit = mk3(rng01(path.key, 0u) * (js - (-js)) + (-js), rng01(path.key, 1u) * (js - (-js)) + (-js),
@@ -1742,6 +1746,9 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     P.W = W;
     P.H = H;
     P.tiles_x = (W + 7) / 8;
+    P.div_tiles_x = make_fastdiv((uint32_t)P.tiles_x);
+    P.div_per_tile = make_fastdiv(64u);
+    P.seed_hash = pcg(o.seed);
     const uint32_t tiles = (uint32_t)P.tiles_x * (uint32_t)((H + 7) / 8);
     P.tile_rank = o.tile_rank;
     P.tile_world = o.tile_world;
@@ -1861,6 +1868,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         RT_HIP_CHECK(ctx, hipMemsetAsync(pp.d_levels, 0, (size_t)(levels + 1) * kSubQueues * 32 * sizeof(unsigned int), pp.stream));
         P.colors = pp.d_colors;
         P.S = s_now;
+        P.div_per_tile = make_fastdiv(64u * (uint32_t)s_now);
         P.chunk_first = first + done;
         P.n_items = (uint32_t)((size_t)s_now * items_per_sample);
         P.sub_cap = (((P.n_items + 63u) / 64u) / (uint32_t)kSubQueues + 66u) * 64u;

@@ -218,3 +218,13 @@ def test_bvh_wireframe_boxes_follow_the_reference_visualiser(tmp_path):
     boxes = bvhdebug.wireframe_boxes(old, 0, 40)
     assert sum(b[3] for b in boxes) == 6 and sum(not b[3] for b in boxes) == 5
     assert [b[2] for b in boxes if not b[3]][0] == 0
+
+
+def test_fastdiv_is_exact(tmp_path):
+    """The camera-ray generator divides by launch-time constants through a multiply-high (csrc/fastdiv.hpp); checked against
+    the machine's own divide around the multiples of a few thousand divisors, at both ends of the 32-bit range and at random."""
+    import subprocess
+    exe = str(tmp_path / "fastdiv_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "native", "fastdiv_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
