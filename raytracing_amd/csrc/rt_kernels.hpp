@@ -1,0 +1,565 @@
+// rt_kernels.hpp: path state, shading, camera rays, and the wavefront kernels k_path, k_refill, k_fold -- part of rt_hip.hip (included there, inside its unnamed namespace); see that file for the overall design.
+#pragma once
+
+// Path state carried from one bounce level to the next.
+struct Path {
+    f3 o, d, inv; // current ray
+    float4 thr;   // throughput (w used by the old-scene estimator only)
+    float rr;     // old-scene estimator: roulette weight of the current depth
+    int depth;    // traversals already started on this path
+    uint32_t key; // RNG key of (pixel, sample)
+};
+
+// Shades one finished closest-hit search: the path either ENDS (its colour goes to colors[sample][pixel]; returns
+// true) or CONTINUES with a new ray in `path` (returns false).  Also records the primary-hit id of the first sample.
+template <bool OLD, bool STATS>
+RT_D bool shade_path(const KParams &P, Path &path, const Best &hit, const uint32_t cidx, Cnt &cnt) {
+    bool ended = false;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t dim = 3u + 4u * (uint32_t)path.depth;
+    const bool first = path.depth == 0;
+    path.depth++;
+    uint32_t prim = kNone;
+    if (!OLD) { // Trace::CastRay(ray, depth, sd::DataStorage&), CPURayTrace/Trace.cpp:58-96
+        if (hit.ref != kNone) {
+            if (STATS)
+                cnt.trih++;
+            const float4 q2 = P.tri_pos[3 * hit.ref + 2];
+            prim = __float_as_uint(q2.y);
+            if (__float_as_uint(q2.z) == 0u) { // LambertianMat; otherwise the same ray is cast again (Trace.cpp:80-82)
+                f3 N = tri_normal(P, hit.ref, hit.u, hit.v);
+                f3 pos = path.o + hit.t * path.d;
+                f3 bias = N * 1e-5f; // Lambertian::Hit, Materials/Lambertian.hpp:35-48
+                float u1 = rng01(path.key, dim + 1u);
+                float u2 = rng01(path.key, dim + 2u);
+                path.d = cosine_dir(N, u1, u2);
+                path.o = pos + bias;
+                path.thr = make_float4(path.thr.x * 0.9f, path.thr.y * 0.6f, path.thr.z * 0.5f, 1.f);
+            }
+            ended = !(path.depth < P.bounce_limit); // loop condition of Trace.cpp:63: colour stays (0,0,0,0)
+        } else {
+            f3 sk = sky_color(path.d);
+            c = make_float4(0.f + path.thr.x * sk.x, 0.f + path.thr.y * sk.y, 0.f + path.thr.z * sk.z, 0.f + 1.0f);
+            ended = true;
+        }
+    } else { // Trace::CastRay(ray, depth, const Scene&), CPURayTrace/Trace.cpp:31-56, products taken front to back
+        const float rr = path.rr;
+        if (hit.ref == kNone) {
+            f3 sk = sky_color(path.d);
+            c = make_float4((path.thr.x * sk.x) * rr, (path.thr.y * sk.y) * rr, (path.thr.z * sk.z) * rr,
+                            (path.thr.w * 1.0f) * rr);
+            ended = true;
+        } else {
+            f3 pos = path.o + hit.t * path.d;
+            f3 N;
+            uint32_t mat;
+            if (hit.ref & kSphereBit) {
+                const uint32_t si = hit.ref & ~kSphereBit;
+                const float4 s0 = P.spheres[2 * si], s1 = P.spheres[2 * si + 1];
+                N = normalize3(pos - mk3(s0.x, s0.y, s0.z));
+                mat = __float_as_uint(s1.x);
+                prim = __float_as_uint(s1.y);
+            } else {
+                if (STATS)
+                    cnt.trih++;
+                const float4 q2 = P.tri_pos[3 * hit.ref + 2];
+                N = tri_normal(P, hit.ref, hit.u, hit.v);
+                prim = __float_as_uint(q2.y);
+                mat = __float_as_uint(q2.z);
+            }
+            const float4 m0 = P.mats[2 * mat], m1 = P.mats[2 * mat + 1];
+            const uint32_t mkind = __float_as_uint(m1.x);
+            const float param = m1.y;
+            path.thr = make_float4((path.thr.x * m0.x) * rr, (path.thr.y * m0.y) * rr, (path.thr.z * m0.z) * rr,
+                                   (path.thr.w * m0.w) * rr);
+            if (mkind == RT_MAT_EMIT) { // LightEmit::getIrradiance, Materials/LightEmit.hpp:11-14
+                c = path.thr;
+                ended = true;
+            } else {
+                f3 no, nd;
+                if (mkind == RT_MAT_DIELECTRIC) { // no reference counterpart: Snell + Schlick
+                    f3 unit = normalize3(path.d);
+                    bool front = dot3(unit, N) < 0.0f;
+                    f3 nn = front ? N : -N;
+                    float ri = front ? (1.0f / param) : param;
+                    float dn = dot3(-unit, nn);
+                    float cosT = (1.0f < dn) ? 1.0f : dn;
+                    float sinT = sqrtf(1.0f - cosT * cosT);
+                    bool cannot = ri * sinT > 1.0f;
+                    float pick = rng01(path.key, dim + 3u);
+                    f3 bias = nn * 1e-4f;
+                    if (cannot || reflectance(cosT, ri) > pick) {
+                        nd = unit - nn * dot3(unit, nn) * 2.f;
+                        no = pos + bias;
+                    } else {
+                        f3 perp = ri * (unit + cosT * nn);
+                        f3 par = nn * -sqrtf(fabsf(1.0f - dot3(perp, perp)));
+                        nd = perp + par;
+                        no = pos - bias;
+                    }
+                } else { // Lambertian (Materials/Lambertian.hpp:16-29) or Metal (Materials/Metal.hpp:15-31)
+                    f3 bias = N * 1e-4f;
+                    float u1 = rng01(path.key, dim + 1u);
+                    float u2 = rng01(path.key, dim + 2u);
+                    f3 rnd = cosine_dir(N, u1, u2);
+                    if (mkind == RT_MAT_METAL) {
+                        f3 refl = path.d - N * dot3(path.d, N) * 2.f;
+                        nd = normalize3(rnd * param + refl * (1 - param));
+                    } else {
+                        nd = rnd;
+                    }
+                    no = pos + bias;
+                }
+                path.o = no;
+                path.d = nd;
+                // entry test of the next CastRay call (Trace.cpp:33-38): roulette, then the depth cap
+                float nrr = 1.0f;
+                if (path.depth > 1)
+                    nrr = rng01(path.key, 3u + 4u * (uint32_t)path.depth) < 0.8f ? 1.0f / 0.8f : 0.0f;
+                if (path.depth > P.bounce_limit || nrr == 0.0f)
+                    ended = true; // that call returns zero
+                path.rr = nrr;
+            }
+        }
+    }
+    if (first && P.primary != nullptr && P.chunk_first + (int)(cidx / P.npix) == P.first_sample)
+        P.primary[cidx % P.npix] = prim;
+    if (ended)
+        P.colors[cidx] = c;
+    return ended;
+}
+
+// Camera ray of work item `item` = (tile ordinal, sample in chunk, pixel in the 8x8 tile); returns false for a pixel
+// outside the image (or when the estimator starts no traversal at all).
+template <bool OLD>
+RT_D bool camera_path(const KParams &P, const uint32_t item, Path &path, uint32_t &cidx) {
+    const uint32_t per_tile = 64u * (uint32_t)P.S;
+    const uint32_t j = fastdiv(item, P.div_per_tile);
+    const uint32_t s = (item - j * per_tile) >> 6;
+    const uint32_t in_tile = item & 63u;
+    const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
+    const uint32_t tile_y = fastdiv(tile, P.div_tiles_x);
+    const int x = (int)(tile - tile_y * (uint32_t)P.tiles_x) * 8 + (int)(in_tile & 7u);
+    const int y = (int)tile_y * 8 + (int)(in_tile >> 3);
+    bool live = item < P.n_items && x < P.W && y < P.H;
+    const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+    const int n = P.chunk_first + (int)s;
+    cidx = s * P.npix + pixel;
+    // CPUImageData::uvAt, Renderer/TraceMethods.hpp:30; Camera::getRayDirction, Camera.hpp:33-47
+    const float u = (float)x / (float)P.W, v = (float)y / (float)P.H;
+    f3 view = normalize3(mk3(u * P.cam_w - P.cam_w / 2, v * P.cam_h - P.cam_h / 2, P.focal));
+    view.x = -view.x;
+    const f3 dir0 = basis_mul(P.bx, P.by, P.bz, view);
+    path.key = pcg(pcg(P.seed_hash + pixel) + (uint32_t)n + P.sample_offset);
+    // glm::linearRand(vec3(-s), vec3(s)), Include/Random.hpp:13-16
+    const float js = P.jitter;
+    f3 jit = mk3(rng01(path.key, 0u) * (js - (-js)) + (-js), rng01(path.key, 1u) * (js - (-js)) + (-js),
+                 rng01(path.key, 2u) * (js - (-js)) + (-js));
+    path.o = P.cam_pos;
+    path.d = dir0 + jit;
+    path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
+    path.rr = 1.0f;
+    path.depth = 0;
+    if (!OLD && P.bounce_limit <= 0) { // Trace.cpp:63: no traversal at all, the sample is (0,0,0,0)
+        if (live) {
+            P.colors[cidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (P.primary != nullptr && n == P.first_sample)
+                P.primary[pixel] = kNone;
+        }
+        live = false;
+    }
+    return live;
+}
+
+// Wavefront path kernel: one launch per bounce level.
+//
+// Level 0 generates the camera rays of `S` consecutive samples of every pixel this context owns.  A
+// wave takes 64 work items at a time; items are numbered (tile, sample, pixel in
+// the 8x8 tile), so the 64 rays of a batch are the camera rays of one tile for one sample and stay
+// coherent.  After the closest-hit search a path either ENDS -- its colour is stored in the per-sample
+// colour buffer, colors[sample][pixel] -- or CONTINUES: its state is appended to the queue of the next
+// level, which the next launch consumes 64 records per wave.  Paths of every depth therefore run in
+// full waves, and no lane ever waits for a neighbour's longer path.  The per-sample colours are folded
+// into the running mean afterwards, in sample order, by k_fold, which reproduces the reference's
+// "pixel = (pixel*(n-1) + new)/n" (Renderer/TraceMethods.cpp:59) bit for bit.
+constexpr int WALK_LANE = 0, WALK_WAVE = 1, WALK_FAST = 2, WALK_BRUTE = 3;
+template <bool OLD, bool STATS, int WALK>
+__global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const KParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    // Level 0: items are camera rays, batch b = items 64 b .. 64 b + 63.  Deeper levels: the queue is kSubQueues
+    // sub-queues, each filled by the level before through its own append counter; lane q of every wave reads count
+    // q, and a wave scan gives the level's total number of batches (for the tail decision and the early return).
+    uint32_t sub_count = 0u, sub_end = 0u; // lane q: records in sub-queue q; batches in sub-queues 0..q
+    uint32_t n_batches;
+    if (P.level == 0) {
+        n_batches = (P.n_items + 63u) >> 6;
+    } else {
+        sub_count = P.sub_in[lane * 32u];
+        sub_end = (sub_count + 63u) >> 6;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)sub_end, off, 64);
+            if ((int)lane >= off)
+                sub_end += up;
+        }
+        n_batches = (uint32_t)__builtin_amdgcn_readlane((int)sub_end, 63);
+    }
+    const uint32_t n_in = P.level == 0 ? P.n_items : n_batches * 64u;
+    // A level with too few rays to fill the chip is bound by the latency of one walk, which is shortest
+    // when every lane walks alone; a level that saturates the chip is bound by throughput.
+    const bool use_wave = WALK == WALK_WAVE && n_in >= P.wave_min_rays;
+    // Tail mode: when a level holds too few rays to fill the chip, its launch lasts as long as its single longest
+    // walk, and so would every launch after it; instead each lane then follows its path to the end, and the launches
+    // of the deeper levels find their queues empty and return at once.
+    const bool tail = P.tail != 0 || (P.level >= 1 && n_in <= kTailRays);
+    // Batches of 64 items are dealt to the waves round-robin: one shared cursor would be hit by half a million
+    // same-address atomics per launch at level 0, which alone takes longer than the rays.  Neighbouring
+    // batches (the samples of one tile, tiles of one image row) go to different waves, so the expensive part of
+    // the image is spread over the whole grid.
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Work distribution: the waves with wave_id % 64 == q form group q and draw batches from that group's own cursor
+    // (64 cursors in separate cache lines: atomics on one address are serialised at about 10 ns each), so a wave
+    // that met long walks simply draws fewer batches.  Level 0: group q owns the batches q, q + 64, q + 128, ... of
+    // camera rays and draws them kChunk at a time.  Deeper levels: group q owns sub-queue q.
+    constexpr uint32_t kChunk = 4u;
+    const uint32_t my_q = wave_id & (uint32_t)(kSubQueues - 1);
+    const uint32_t my_count = P.level == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sub_count, (int)my_q);
+    const uint32_t my_batches = P.level == 0 ? (n_batches > my_q ? (n_batches - my_q + (uint32_t)kSubQueues - 1u) / (uint32_t)kSubQueues : 0u)
+                                             : (my_count + 63u) >> 6;
+    const uint32_t chunk = P.level == 0 ? kChunk : 1u;
+    uint32_t next = 0u, left = 0u; // next batch of the group this wave may take, and how many of its chunk remain
+    for (;;) {
+        if (left == 0u) {
+            unsigned int b = 0;
+            if (lane == 0)
+                b = atomicAdd(P.sub_cursor + my_q * 32u, chunk);
+            next = __builtin_amdgcn_readfirstlane(b);
+            left = chunk;
+        }
+        const uint32_t b = next;
+        if (b >= my_batches)
+            break;
+        next++;
+        left--;
+        uint32_t g, out_q; // g: item number (level 0) or record number in the queue; out_q: sub-queue continuing paths go to
+        bool live;
+        if (P.level == 0) {
+            const uint32_t batch = my_q + b * (uint32_t)kSubQueues;
+            g = batch * 64u + lane;
+            live = g < n_in;
+            out_q = my_q;
+        } else {
+            const uint32_t local = b * 64u + lane;
+            live = local < my_count;
+            g = my_q * P.sub_cap + local;
+            out_q = (my_q + b) & (uint32_t)(kSubQueues - 1);
+        }
+        Path path;
+        uint32_t cidx = 0;
+        if (P.level == 0) {
+            live = camera_path<OLD>(P, g, path, cidx);
+        } else {
+            path.o = path.d = mk3(1.f, 1.f, 1.f);
+            path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
+            path.rr = 1.0f;
+            path.depth = 0;
+            path.key = 0;
+            if (live) {
+                const float4 r0 = P.q_in[4 * (size_t)g], r1 = P.q_in[4 * (size_t)g + 1], r2 = P.q_in[4 * (size_t)g + 2],
+                             r3 = P.q_in[4 * (size_t)g + 3];
+                path.o = mk3(r0.x, r0.y, r0.z);
+                path.d = mk3(r0.w, r1.x, r1.y);
+                path.thr = make_float4(r1.z, r1.w, r2.x, r2.y);
+                path.rr = r2.z;
+                path.key = __float_as_uint(r2.w);
+                cidx = __float_as_uint(r3.x);
+                path.depth = (int)__float_as_uint(r3.y);
+            }
+        }
+        bool ended = false;
+        // One pass = one closest-hit search and its shading.  In tail mode (the deep levels, whose few rays cannot
+        // fill the chip and whose launches each last as long as their single longest walk) a lane keeps its path
+        // until it ends, instead of handing it to another launch.
+        for (;;) {
+        if (__ballot(live) == 0ull)
+            break;
+        path.inv = mk3(1.0f / path.d.x, 1.0f / path.d.y, 1.0f / path.d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
+        // ---- one closest-hit search per lane ----
+        Best hit;
+        if (live)
+            cnt.rays++;
+        if (WALK == WALK_WAVE && use_wave) {
+            closest_hit_wave<OLD, STATS>(P, live, path.o, path.d, path.inv, hit, cnt);
+        } else {
+            hit.ref = kNone;
+            hit.t = 0.f;
+            hit.u = hit.v = 0.f;
+            if (live) {
+                if (WALK == WALK_FAST)
+                    closest_hit_fast<OLD, STATS>(P, path.o, path.d, path.inv, hit, cnt);
+                else if (WALK == WALK_BRUTE)
+                    closest_hit_brute<OLD, STATS>(P, path.o, path.d, hit, cnt);
+                else
+                    closest_hit<OLD, STATS>(P, path.o, path.d, path.inv, hit, cnt);
+            }
+        }
+        // ---- shade: the path ends with a colour or continues with a new ray ----
+        ended = false;
+        if (live)
+            ended = shade_path<OLD, STATS>(P, path, hit, cidx, cnt);
+        if (!tail)
+            break;
+        live = live && !ended;
+        }
+        if (tail)
+            continue;
+        // ---- continuing paths go to the next level's queue, compacted per wave ----
+        const bool cont = live && !ended;
+        const unsigned long long cmask = __ballot(cont);
+        if (cmask != 0ull) {
+            const uint32_t q = out_q;
+            unsigned int obase = 0;
+            if (lane == 0)
+                obase = atomicAdd(P.sub_out + q * 32u, (unsigned int)__builtin_popcountll(cmask));
+            obase = __builtin_amdgcn_readfirstlane(obase);
+            if (cont) {
+                const size_t slot = (size_t)q * P.sub_cap + (size_t)obase + (size_t)__builtin_popcountll(cmask & ((1ull << lane) - 1ull));
+                P.q_out[4 * slot] = make_float4(path.o.x, path.o.y, path.o.z, path.d.x);
+                P.q_out[4 * slot + 1] = make_float4(path.d.y, path.d.z, path.thr.x, path.thr.y);
+                P.q_out[4 * slot + 2] = make_float4(path.thr.z, path.thr.w, path.rr, __uint_as_float(path.key));
+                P.q_out[4 * slot + 3] = make_float4(__uint_as_float(cidx), __uint_as_float((uint32_t)path.depth), 0.f, 0.f);
+            }
+        }
+    }
+    // Counters: one atomic per wave that has something to add.  (Thousands of same-address atomics are
+    // serialised by the memory system; a launch whose level is empty must not pay for them.)
+    if (n_batches == 0u)
+        return;
+    unsigned long long r = wave_sum(cnt.rays);
+    if (lane == 0 && r != 0ull)
+        atomicAdd(counter_slot(P, wave_id, 0), r);
+    if (STATS) {
+        unsigned long long b = wave_sum(cnt.box), t = wave_sum(cnt.tri), s = wave_sum(cnt.sph), h = wave_sum(cnt.trih);
+        if (lane == 0 && r != 0ull) {
+            atomicAdd(counter_slot(P, wave_id, 1), b);
+            atomicAdd(counter_slot(P, wave_id, 2), t);
+            atomicAdd(counter_slot(P, wave_id, 3), s);
+            atomicAdd(counter_slot(P, wave_id, 4), h);
+        }
+    }
+    if (WALK == WALK_FAST) {
+        unsigned long long rp = wave_sum(cnt.replay);
+        if (lane == 0 && rp != 0ull)
+            atomicAdd(counter_slot(P, wave_id, 5), rp);
+    }
+}
+
+// Path kernel of the fast walk with lane re-fill (one launch per bounce level, like k_path).
+//
+// Walk lengths are heavy-tailed, so a wave that takes 64 rays and walks until the longest one is done has, at the
+// bounce levels, about 11 of its 64 lanes busy per instruction.  Here a lane that finishes its walk does not wait for
+// the wave: the wave walks in bursts of kBurst records; when kServiceLanes lanes have finished (or none is left
+// walking) it shades the finished ones together -- a path ENDS (colour stored) or CONTINUES (appended to the next
+// level's queue, or, in tail mode, walked on by the same lane) -- and hands the free lanes the next items of the
+// batch the wave holds, drawing a new batch from its group's cursor when that one is used up.  Same per-ray
+// arithmetic as k_path, same results.
+constexpr int kBurst = 16;
+constexpr uint32_t kServiceLanes = 24;
+constexpr size_t kRefillSceneBytes = 32u << 20; // 8 XCDs x 4 MB of L2
+
+template <bool OLD, bool STATS>
+__global__ void __launch_bounds__(256) k_refill(const KParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    uint32_t sub_count = 0u, sub_end = 0u;
+    uint32_t n_batches;
+    if (P.level == 0) {
+        n_batches = (P.n_items + 63u) >> 6;
+    } else {
+        sub_count = P.sub_in[lane * 32u];
+        sub_end = (sub_count + 63u) >> 6;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)sub_end, off, 64);
+            if ((int)lane >= off)
+                sub_end += up;
+        }
+        n_batches = (uint32_t)__builtin_amdgcn_readlane((int)sub_end, 63);
+    }
+    if (n_batches == 0u)
+        return;
+    const bool tail = P.tail != 0 || (P.level >= 1 && n_batches * 64u <= kTailRays);
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t my_q = wave_id & (uint32_t)(kSubQueues - 1);
+    const uint32_t my_count = P.level == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sub_count, (int)my_q);
+    const uint32_t my_batches = P.level == 0 ? (n_batches > my_q ? (n_batches - my_q + (uint32_t)kSubQueues - 1u) / (uint32_t)kSubQueues : 0u)
+                                             : (my_count + 63u) >> 6;
+    const uint32_t n = P.n_fnodes * 32u;
+    // the batch the wave is handing out, and how many of its 64 items are gone (64 = none held)
+    uint32_t cur_b = 0u, used = 64u;
+    bool drained = my_batches == 0u; // the group's cursor has run past its last batch
+    // lane state
+    bool has = false;
+    Path path;
+    path.o = path.d = path.inv = mk3(1.f, 1.f, 1.f);
+    path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
+    path.rr = 1.0f;
+    path.depth = 0;
+    path.key = 0u;
+    uint32_t cidx = 0u, out_q = 0u;
+    Walk w = {n, kNone, kNone, 0.0f};
+    Best best = {__builtin_inff(), 0.0f, 0.0f, kNone};
+    uint32_t bpos = kNone;
+    float bm = 0.0f;
+    auto start_walk = [&]() {
+        path.inv = mk3(1.0f / path.d.x, 1.0f / path.d.y, 1.0f / path.d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
+        w = Walk{0u, kNone, kNone, 0.0f};
+        best = Best{__builtin_inff(), 0.0f, 0.0f, kNone};
+        bpos = kNone;
+        bm = 0.0f;
+        cnt.rays++;
+    };
+    for (;;) {
+        // ---- free lanes take the next items of the held batch; a used-up batch is replaced from the group's cursor ----
+        for (;;) {
+            const unsigned long long empty = __ballot(!has);
+            if (empty == 0ull)
+                break;
+            if (used >= 64u) {
+                if (drained)
+                    break;
+                unsigned int b = 0;
+                if (lane == 0)
+                    b = atomicAdd(P.sub_cursor + my_q * 32u, 1u);
+                cur_b = __builtin_amdgcn_readfirstlane(b);
+                if (cur_b >= my_batches) {
+                    drained = true;
+                    break;
+                }
+                used = 0u;
+            }
+            const uint32_t item = used + (uint32_t)__builtin_popcountll(empty & below); // item of the held batch for this lane
+            if (!has && item < 64u) {
+                if (P.level == 0) {
+                    has = camera_path<OLD>(P, (my_q + cur_b * (uint32_t)kSubQueues) * 64u + item, path, cidx);
+                    out_q = my_q;
+                } else if (cur_b * 64u + item < my_count) {
+                    const size_t g = (size_t)my_q * P.sub_cap + (size_t)cur_b * 64u + item;
+                    const float4 r0 = P.q_in[4 * g], r1 = P.q_in[4 * g + 1], r2 = P.q_in[4 * g + 2], r3 = P.q_in[4 * g + 3];
+                    path.o = mk3(r0.x, r0.y, r0.z);
+                    path.d = mk3(r0.w, r1.x, r1.y);
+                    path.thr = make_float4(r1.z, r1.w, r2.x, r2.y);
+                    path.rr = r2.z;
+                    path.key = __float_as_uint(r2.w);
+                    cidx = __float_as_uint(r3.x);
+                    path.depth = (int)__float_as_uint(r3.y);
+                    out_q = (my_q + cur_b) & (uint32_t)(kSubQueues - 1);
+                    has = true;
+                }
+                if (has)
+                    start_walk();
+            }
+            const uint32_t taken = (uint32_t)__builtin_popcountll(empty);
+            used = used + taken < 64u ? used + taken : 64u;
+            if (used < 64u)
+                break; // every free lane was served
+        }
+        if (__ballot(has) == 0ull)
+            break; // nothing in flight and nothing left to hand out
+        // ---- walk in bursts until enough lanes wait for service ----
+        for (;;) {
+            if (has && w.idx < n) {
+                fast_walk_from<OLD, STATS, kBurst>(P, path.o, path.d, path.inv, w, cnt, [&](const Cand &c) {
+                    if ((c.t < best.t || (c.t == best.t && c.pos < bpos)) && c.t < __builtin_inff()) {
+                        best = Best{c.t, c.u, c.v, c.ref};
+                        bpos = c.pos;
+                        bm = fmaxf(c.m, c.mesh_m);
+                    }
+                });
+            }
+            const unsigned long long walking = __ballot(has && w.idx < n);
+            if (walking == 0ull)
+                break;
+            const uint32_t finished = (uint32_t)__builtin_popcountll(__ballot(has && !(w.idx < n)));
+            const uint32_t fillable = drained && used >= 64u ? 0u : (uint32_t)__builtin_popcountll(__ballot(!has));
+            if (finished + fillable >= kServiceLanes)
+                break;
+        }
+        // ---- shade the finished walks ----
+        bool cont = false;
+        if (has && !(w.idx < n)) {
+            if (best.ref != kNone && (bm > best.t || P.force_replay != 0)) { // see closest_hit_fast
+                cnt.replay++;
+                replay_ordered<OLD, STATS>(P, path.o, path.d, path.inv, best, cnt);
+            }
+            const bool ended = shade_path<OLD, STATS>(P, path, best, cidx, cnt);
+            if (ended) {
+                has = false;
+            } else if (tail) {
+                start_walk();
+            } else {
+                cont = true;
+                has = false;
+            }
+        }
+        // continuing paths go to the next level's queue: the sub-queue their batch feeds, compacted per wave
+        unsigned long long cmask = __ballot(cont);
+        while (cmask != 0ull) {
+            const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)out_q, __builtin_ctzll(cmask));
+            const unsigned long long qmask = __ballot(cont && out_q == q);
+            unsigned int obase = 0;
+            if (lane == 0)
+                obase = atomicAdd(P.sub_out + q * 32u, (unsigned int)__builtin_popcountll(qmask));
+            obase = __builtin_amdgcn_readfirstlane(obase);
+            if (cont && out_q == q) {
+                const size_t slot = (size_t)q * P.sub_cap + (size_t)obase + (size_t)__builtin_popcountll(qmask & below);
+                P.q_out[4 * slot] = make_float4(path.o.x, path.o.y, path.o.z, path.d.x);
+                P.q_out[4 * slot + 1] = make_float4(path.d.y, path.d.z, path.thr.x, path.thr.y);
+                P.q_out[4 * slot + 2] = make_float4(path.thr.z, path.thr.w, path.rr, __uint_as_float(path.key));
+                P.q_out[4 * slot + 3] = make_float4(__uint_as_float(cidx), __uint_as_float((uint32_t)path.depth), 0.f, 0.f);
+            }
+            cmask &= ~qmask;
+        }
+    }
+    unsigned long long r = wave_sum(cnt.rays);
+    if (lane == 0 && r != 0ull)
+        atomicAdd(counter_slot(P, wave_id, 0), r);
+    if (STATS) {
+        unsigned long long b = wave_sum(cnt.box), t = wave_sum(cnt.tri), sp = wave_sum(cnt.sph), h = wave_sum(cnt.trih);
+        if (lane == 0 && r != 0ull) {
+            atomicAdd(counter_slot(P, wave_id, 1), b);
+            atomicAdd(counter_slot(P, wave_id, 2), t);
+            atomicAdd(counter_slot(P, wave_id, 3), sp);
+            atomicAdd(counter_slot(P, wave_id, 4), h);
+        }
+    }
+    unsigned long long rp = wave_sum(cnt.replay);
+    if (lane == 0 && rp != 0ull)
+        atomicAdd(counter_slot(P, wave_id, 5), rp);
+}
+
+// Folds the S per-sample colours of every owned pixel into the running mean, in sample order:
+// pixel = (pixel*(n-1) + colour_n)/n, Renderer/TraceMethods.cpp:59.
+__global__ void __launch_bounds__(256) k_fold(float4 *image, const float4 *colors, uint32_t npix, int W, int tiles_x,
+                                              int tile_rank, int tile_world, int chunk_first, int S) {
+    const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
+    if (pixel >= npix)
+        return;
+    if (tile_world > 1) {
+        const uint32_t x = pixel % (uint32_t)W, y = pixel / (uint32_t)W;
+        const uint32_t tile = (y >> 3) * (uint32_t)tiles_x + (x >> 3);
+        if ((int)(tile % (uint32_t)tile_world) != tile_rank)
+            return;
+    }
+    float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (chunk_first > 1)
+        px = image[pixel];
+    for (int s = 0; s < S; s++) {
+        const int n = chunk_first + s;
+        const float4 c = colors[(size_t)s * npix + pixel];
+        const float nm1 = static_cast<float>((float)n - 1.f), nf = static_cast<float>(n);
+        px = make_float4((px.x * nm1 + c.x) / nf, (px.y * nm1 + c.y) / nf, (px.z * nm1 + c.z) / nf, (px.w * nm1 + c.w) / nf);
+    }
+    image[pixel] = px;
+}
+

@@ -1,0 +1,855 @@
+// rt_walks.hpp: closest-hit searches (reference-order lane / wave walks, brute force, the fast walk and its ordered replay) and the first-generation kernel k_trace -- part of rt_hip.hip (included there, inside its unnamed namespace); see that file for the overall design.
+#pragma once
+
+struct Best {
+    float t, u, v;
+    uint32_t ref; // triangle slot, kSphereBit | sphere index, or kNone
+};
+struct Cnt {
+    unsigned long long rays, box, tri, sph, trih, replay;
+};
+
+// Closest hit in the reference's own visiting order.  One iteration = one node of the reference
+// traversal: slab test against (1e-6, closest.t) (SimplifiedData.cpp:443, BVH.hpp:129), then for a
+// leaf the primitive test and the strict "t < closest.t" update (SimplifiedData.cpp:452, BVH.hpp:137).
+// The per-axis early-outs of the reference slab test only stop early; the accept/reject decision is
+// the final "tMax <= tMin" comparison because tMin never decreases and tMax never increases.
+template <bool OLD, bool STATS>
+RT_D void closest_hit(const KParams &P, const f3 o, const f3 d, const f3 inv, Best &best, Cnt &cnt) {
+    best.t = __builtin_inff();
+    best.u = 0.0f;
+    best.v = 0.0f;
+    best.ref = kNone;
+    Best outer = best;         // OLD: the scene-level closest while inside a mesh's inner BVH
+    uint32_t inner_end = kNone; // OLD: first node index after the current mesh's inner BVH
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const uint32_t n = P.n_nodes * 32u; // node records are addressed by byte offset (32 bytes each)
+    uint32_t idx = 0;
+    while (idx < n) {
+        if (OLD) {
+            if (idx == inner_end) { // Mesh::intersect returned: keep it only if strictly closer (BVH.hpp:137)
+                if (!(best.t < outer.t))
+                    best = outer;
+                inner_end = kNone;
+            }
+        }
+        const float4 *rec = (const float4 *)((const char *)P.nodes + idx);
+        const float4 a = rec[0];
+        const float4 b = rec[1];
+        const uint32_t skip = __float_as_uint(b.z);
+        const uint32_t kind = __float_as_uint(b.w);
+        if (STATS)
+            cnt.box++;
+        float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
+        float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
+        float t0z = (a.z - o.z) * inv.z, t1z = (b.y - o.z) * inv.z;
+        float nearx = nx ? t1x : t0x, farx = nx ? t0x : t1x;
+        float neary = ny ? t1y : t0y, fary = ny ? t0y : t1y;
+        float nearz = nz ? t1z : t0z, farz = nz ? t0z : t1z;
+        // "t0 > tMin ? t0 : tMin" keeps tMin when t0 is NaN, as fmaxf(t0, tMin) does; likewise fminf
+        float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+        float tmax = fminf(farz, fminf(fary, fminf(farx, best.t)));
+        if (tmax <= tmin) {
+            idx = skip;
+            continue;
+        }
+        idx = idx + 32u;
+        const uint32_t k = kind & 7u;
+        if (k == KIND_INTERNAL)
+            continue;
+        const uint32_t slot = kind >> 3;
+        if (k == KIND_TRI) {
+            if (STATS)
+                cnt.tri++;
+            const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
+            const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+            const float EPSILON = 1e-7f;
+            f3 h = cross3(d, e2);
+            float det = dot3(e1, h);
+            if (!(det > -EPSILON && det < EPSILON)) {
+                float f = 1.0f / det;
+                f3 s = o - p0;
+                float u = f * dot3(s, h);
+                if (!(u < 0.0f || u > 1.0f)) {
+                    f3 q = cross3(s, e1);
+                    float v = f * dot3(d, q);
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        float t = f * dot3(e2, q);
+                        if (t > EPSILON && t < best.t) {
+                            best.t = t;
+                            best.u = u;
+                            best.v = v;
+                            best.ref = slot;
+                        }
+                    }
+                }
+            }
+        } else if (OLD && k == KIND_SPHERE) { // Sphere::intersect, Objects.hpp:43-72
+            if (STATS)
+                cnt.sph++;
+            const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
+            f3 oc = mk3(s0.x, s0.y, s0.z) - o;
+            float qa = dot3(d, d);
+            float qb = -2.0f * dot3(d, oc);
+            float qc = dot3(oc, oc) - s0.w * s0.w;
+            float disc = qb * qb - 4 * qa * qc;
+            if (!(disc < 0)) {
+                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
+                bool ok = !(t < 0);
+                // a ray that starts inside never hits (Objects.hpp:57-60), except for the dielectric
+                // spheres this build adds, which need the exit point
+                if (!ok && __float_as_uint(s1.z) != 0u) {
+                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
+                    ok = !(t < 0);
+                }
+                if (ok && t < best.t) {
+                    best.t = t;
+                    best.ref = kSphereBit | slot;
+                }
+            }
+        } else if (OLD && k == KIND_MESH) { // Mesh::intersect starts a fresh closest hit (Mesh.hpp:154-160)
+            outer = best;
+            inner_end = skip;
+            best.t = __builtin_inff();
+            best.ref = kNone;
+        }
+    }
+    if (OLD) {
+        if (inner_end != kNone) {
+            if (!(best.t < outer.t))
+                best = outer;
+        }
+    }
+}
+
+// "BVH acceleration" switched off (BVHSettings::toggleBVHAccel, Program/BVHUI.hpp:14): every primitive is tested, no
+// box is.  Old scene: Scene::intersectClosest (Program/Scene.hpp:83-95) takes the objects in the order Scene::update
+// left them in -- BVH::build sorts that very vector (BVH.hpp:116-119, :54-65), so it is the left-to-right order of the
+// scene-level leaves, which is the order of the records here -- and accepts "t < closest.t"; a mesh without its inner
+// BVH (Mesh::intersect, Mesh.hpp:161-172) takes its triangles in storage order, which the strict comparison turns into
+// the smallest (t, triangle index).  The flat scene has no such switch in the reference; it is given the same meaning:
+// all triangles in storage order.
+template <bool OLD, bool STATS>
+RT_D void closest_hit_brute(const KParams &P, const f3 o, const f3 d, Best &best, Cnt &cnt) {
+    best = Best{__builtin_inff(), 0.0f, 0.0f, kNone};
+    uint32_t bidx = kNone;      // storage index of the triangle `best` holds
+    Best outer = best;          // OLD: the scene-level closest while inside a mesh
+    uint32_t inner_end = kNone; // OLD: first record after the current mesh's triangles
+    const uint32_t n = P.n_nodes * 32u;
+    for (uint32_t idx = 0; idx < n; idx += 32u) {
+        if (OLD) {
+            if (idx == inner_end) {
+                if (!(best.t < outer.t))
+                    best = outer;
+                inner_end = kNone;
+                bidx = kNone;
+            }
+        }
+        const float4 b = ((const float4 *)((const char *)P.nodes + idx))[1];
+        const uint32_t kind = __float_as_uint(b.w);
+        const uint32_t k = kind & 7u;
+        const uint32_t slot = kind >> 3;
+        if (k == KIND_TRI) {
+            if (STATS)
+                cnt.tri++;
+            const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
+            const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+            const float EPSILON = 1e-7f;
+            f3 h = cross3(d, e2);
+            float det = dot3(e1, h);
+            if (!(det > -EPSILON && det < EPSILON)) {
+                float f = 1.0f / det;
+                f3 s = o - p0;
+                float u = f * dot3(s, h);
+                if (!(u < 0.0f || u > 1.0f)) {
+                    f3 q = cross3(s, e1);
+                    float v = f * dot3(d, q);
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        float t = f * dot3(e2, q);
+                        const uint32_t ti = __float_as_uint(q2.y);
+                        const bool in_order_group = !OLD || inner_end != kNone; // triangles scanned in storage order
+                        if (t > EPSILON && (t < best.t || (in_order_group && t == best.t && t < __builtin_inff() && ti < bidx))) {
+                            best = Best{t, u, v, slot};
+                            bidx = ti;
+                        }
+                    }
+                }
+            }
+        } else if (OLD && k == KIND_SPHERE) { // Sphere::intersect, Objects.hpp:43-72
+            if (STATS)
+                cnt.sph++;
+            const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
+            f3 oc = mk3(s0.x, s0.y, s0.z) - o;
+            float qa = dot3(d, d);
+            float qb = -2.0f * dot3(d, oc);
+            float qc = dot3(oc, oc) - s0.w * s0.w;
+            float disc = qb * qb - 4 * qa * qc;
+            if (!(disc < 0)) {
+                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
+                bool ok = !(t < 0);
+                if (!ok && __float_as_uint(s1.z) != 0u) {
+                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
+                    ok = !(t < 0);
+                }
+                if (ok && t < best.t) {
+                    best = Best{t, 0.0f, 0.0f, kSphereBit | slot};
+                    bidx = kNone;
+                }
+            }
+        } else if (OLD && k == KIND_MESH) { // Mesh::intersect starts a fresh closest hit (Mesh.hpp:154-160)
+            outer = best;
+            inner_end = __float_as_uint(b.z);
+            best = Best{__builtin_inff(), 0.0f, 0.0f, kNone};
+            bidx = kNone;
+        }
+    }
+    if (OLD) {
+        if (inner_end != kNone) {
+            if (!(best.t < outer.t))
+                best = outer;
+        }
+    }
+}
+
+struct RayState {
+    f3 o, d, inv;
+};
+RT_D void set_ray(RayState &r, f3 o, f3 d) { // Ray::Ray, CPURayTrace/Ray.hpp:8
+    r.o = o;
+    r.d = d;
+    r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+}
+
+RT_D f3 tri_normal(const KParams &P, uint32_t slot, float u, float v) { // SimplifiedData.cpp:293
+    const float4 m0 = P.tri_nrm[3 * slot], m1 = P.tri_nrm[3 * slot + 1], m2 = P.tri_nrm[3 * slot + 2];
+    const f3 n0 = mk3(m0.x, m0.y, m0.z), n1 = mk3(m0.w, m1.x, m1.y), n2 = mk3(m1.z, m1.w, m2.x);
+    return normalize3((1 - u - v) * n0 + u * n1 + v * n2);
+}
+
+RT_D float reflectance(float cosine, float ri) {
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    float m = 1.0f - cosine;
+    float m2 = m * m;
+    return r0 + (1.0f - r0) * ((m2 * m2) * m);
+}
+
+// One pixel sample with the flat-scene estimator, Trace::CastRay(ray, depth, sd::DataStorage&),
+// CPURayTrace/Trace.cpp:58-96.
+template <bool STATS>
+RT_D float4 sample_sd(const KParams &P, RayState ray, uint32_t key, Cnt &cnt, uint32_t &primary) {
+    float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
+    f3 thr = mk3(1.f, 1.f, 1.f);
+    int depth = 0;
+    while (depth < P.bounce_limit) {
+        const uint32_t dim = 3u + 4u * (uint32_t)depth;
+        depth++;
+        Best hit;
+        cnt.rays++;
+        closest_hit<false, STATS>(P, ray.o, ray.d, ray.inv, hit, cnt);
+        if (hit.ref != kNone) {
+            if (STATS)
+                cnt.trih++;
+            const float4 q2 = P.tri_pos[3 * hit.ref + 2];
+            if (depth == 1)
+                primary = __float_as_uint(q2.y);
+            if (__float_as_uint(q2.z) != 0u)
+                continue; // not LambertianMat: the reference loop re-casts the unchanged ray (Trace.cpp:80-82)
+            f3 N = tri_normal(P, hit.ref, hit.u, hit.v);
+            f3 pos = ray.o + hit.t * ray.d;
+            // Lambertian::Hit, Materials/Lambertian.hpp:35-48
+            f3 bias = N * 1e-5f;
+            float u1 = rng01(key, dim + 1u);
+            float u2 = rng01(key, dim + 2u);
+            f3 nd = cosine_dir(N, u1, u2);
+            set_ray(ray, pos + bias, nd);
+            thr = thr * mk3(0.9f, 0.6f, 0.5f);
+            continue;
+        }
+        if (depth == 1)
+            primary = kNone;
+        f3 add = thr * sky_color(ray.d);
+        color = make_float4(color.x + add.x, color.y + add.y, color.z + add.z, color.w + 1.0f);
+        break;
+    }
+    return color;
+}
+
+// One pixel sample with the old-scene estimator, Trace::CastRay(ray, depth, const Scene&),
+// CPURayTrace/Trace.cpp:31-56, unrolled into a loop: the recursion multiplies albedo and roulette
+// weights on the way back, the loop multiplies them into a running throughput on the way in.
+template <bool STATS>
+RT_D float4 sample_old(const KParams &P, RayState ray, uint32_t key, Cnt &cnt, uint32_t &primary) {
+    float4 thr = make_float4(1.f, 1.f, 1.f, 1.f);
+    for (int depth = 0;; depth++) {
+        const uint32_t dim = 3u + 4u * (uint32_t)depth;
+        float rr = 1.0f; // Trace.cpp:33, Random::RussianRoulette(0.8f), Include/Random.hpp:74-78
+        if (depth > 1)
+            rr = rng01(key, dim) < 0.8f ? 1.0f / 0.8f : 0.0f;
+        if (depth > P.bounce_limit || rr == 0.0f)
+            return make_float4(0.f, 0.f, 0.f, 0.f);
+        Best hit;
+        cnt.rays++;
+        closest_hit<true, STATS>(P, ray.o, ray.d, ray.inv, hit, cnt);
+        if (hit.ref == kNone) {
+            if (depth == 0)
+                primary = kNone;
+            f3 s = sky_color(ray.d);
+            return make_float4((thr.x * s.x) * rr, (thr.y * s.y) * rr, (thr.z * s.z) * rr, (thr.w * 1.0f) * rr);
+        }
+        f3 pos = ray.o + hit.t * ray.d;
+        f3 N;
+        uint32_t mat, prim;
+        if (hit.ref & kSphereBit) {
+            const uint32_t si = hit.ref & ~kSphereBit;
+            const float4 s0 = P.spheres[2 * si], s1 = P.spheres[2 * si + 1];
+            N = normalize3(pos - mk3(s0.x, s0.y, s0.z));
+            mat = __float_as_uint(s1.x);
+            prim = __float_as_uint(s1.y);
+        } else {
+            if (STATS)
+                cnt.trih++;
+            const float4 q2 = P.tri_pos[3 * hit.ref + 2];
+            N = tri_normal(P, hit.ref, hit.u, hit.v);
+            prim = __float_as_uint(q2.y);
+            mat = __float_as_uint(q2.z);
+        }
+        if (depth == 0)
+            primary = prim;
+        const float4 m0 = P.mats[2 * mat], m1 = P.mats[2 * mat + 1];
+        const uint32_t kind = __float_as_uint(m1.x);
+        const float param = m1.y;
+        thr = make_float4((thr.x * m0.x) * rr, (thr.y * m0.y) * rr, (thr.z * m0.z) * rr, (thr.w * m0.w) * rr);
+        if (kind == RT_MAT_EMIT) // LightEmit::getIrradiance, Materials/LightEmit.hpp:11-14
+            return thr;
+        if (kind == RT_MAT_DIELECTRIC) { // no reference counterpart: Snell + Schlick
+            f3 unit = normalize3(ray.d);
+            bool front = dot3(unit, N) < 0.0f;
+            f3 n = front ? N : -N;
+            float ri = front ? (1.0f / param) : param;
+            float dn = dot3(-unit, n);
+            float cosT = (1.0f < dn) ? 1.0f : dn;
+            float sinT = sqrtf(1.0f - cosT * cosT);
+            bool cannot = ri * sinT > 1.0f;
+            float pick = rng01(key, dim + 3u);
+            f3 bias = n * 1e-4f;
+            if (cannot || reflectance(cosT, ri) > pick) {
+                f3 refl = unit - n * dot3(unit, n) * 2.f;
+                set_ray(ray, pos + bias, refl);
+            } else {
+                f3 perp = ri * (unit + cosT * n);
+                f3 par = n * -sqrtf(fabsf(1.0f - dot3(perp, perp)));
+                set_ray(ray, pos - bias, perp + par);
+            }
+            continue;
+        }
+        // Lambertian::getIrradiance (Materials/Lambertian.hpp:16-29) / Metal::getIrradiance (Metal.hpp:15-31)
+        f3 bias = N * 1e-4f;
+        float u1 = rng01(key, dim + 1u);
+        float u2 = rng01(key, dim + 2u);
+        f3 rnd = cosine_dir(N, u1, u2);
+        if (kind == RT_MAT_METAL) {
+            f3 refl = ray.d - N * dot3(ray.d, N) * 2.f;
+            f3 nd = normalize3(rnd * param + refl * (1 - param));
+            set_ray(ray, pos + bias, nd);
+        } else {
+            set_ray(ray, pos + bias, rnd);
+        }
+    }
+}
+
+// Thousands of atomics on ONE address are serialised by the memory system (about 10 ns each: 80 us for one per
+// wave of a full grid), so counters and queue appends are spread over 64 addresses in separate cache lines.
+RT_D unsigned long long *counter_slot(const KParams &P, uint32_t wave_id, int k) {
+    return P.counters + (size_t)(wave_id & (uint32_t)(kCounterSlots - 1)) * kCounterStride + k;
+}
+RT_D unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Persistent wave64 kernel.  Each wave draws 8x8-pixel tiles from one atomic counter; a lane owns one
+// pixel of the tile and runs that pixel's samples in order, which keeps the reference's running mean
+// "pixel = (pixel*(n-1) + new)/n" (Renderer/TraceMethods.cpp:59) in registers.  Finished lanes drop
+// out of the wave's exec mask; the wave leaves a loop when the mask is empty.
+template <bool OLD, bool STATS>
+__global__ void __launch_bounds__(256) k_trace(const KParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    for (;;) {
+        unsigned int j = 0;
+        if (lane == 0)
+            j = atomicAdd(P.queue, 1u);
+        j = __builtin_amdgcn_readfirstlane(j);
+        if (j >= P.n_my_tiles)
+            break;
+        const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
+        const int x = (int)(tile % (uint32_t)P.tiles_x) * 8 + (int)(lane & 7u);
+        const int y = (int)(tile / (uint32_t)P.tiles_x) * 8 + (int)(lane >> 3);
+        if (x < P.W && y < P.H) {
+            const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+            float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (P.first_sample > 1)
+                px = P.image[pixel];
+            // CPUImageData::uvAt, Renderer/TraceMethods.hpp:30; Camera::getRayDirction, Camera.hpp:33-47
+            const float u = (float)x / (float)P.W, v = (float)y / (float)P.H;
+            f3 view = normalize3(mk3(u * P.cam_w - P.cam_w / 2, v * P.cam_h - P.cam_h / 2, P.focal));
+            view.x = -view.x;
+            const f3 dir0 = basis_mul(P.bx, P.by, P.bz, view);
+            const uint32_t pkey = pcg(pcg(P.seed) + pixel);
+            for (int n = P.first_sample; n < P.first_sample + P.n_samples; n++) {
+                const uint32_t key = pcg(pkey + (uint32_t)n + P.sample_offset);
+                // glm::linearRand(vec3(-s), vec3(s)), Include/Random.hpp:13-16
+                const float s = P.jitter;
+                f3 jit = mk3(rng01(key, 0u) * (s - (-s)) + (-s), rng01(key, 1u) * (s - (-s)) + (-s),
+                             rng01(key, 2u) * (s - (-s)) + (-s));
+                RayState ray;
+                set_ray(ray, P.cam_pos, dir0 + jit);
+                uint32_t prim = kNone;
+                float4 c = OLD ? sample_old<STATS>(P, ray, key, cnt, prim) : sample_sd<STATS>(P, ray, key, cnt, prim);
+                if (P.primary != nullptr && n == P.first_sample)
+                    P.primary[pixel] = prim;
+                const float nm1 = static_cast<float>((float)n - 1.f), nf = static_cast<float>(n);
+                px = make_float4((px.x * nm1 + c.x) / nf, (px.y * nm1 + c.y) / nf, (px.z * nm1 + c.z) / nf,
+                                 (px.w * nm1 + c.w) / nf);
+            }
+            P.image[pixel] = px;
+        }
+    }
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    unsigned long long r = wave_sum(cnt.rays);
+    if (lane == 0 && r != 0ull)
+        atomicAdd(counter_slot(P, wave_id, 0), r);
+    if (STATS) {
+        unsigned long long b = wave_sum(cnt.box), t = wave_sum(cnt.tri), s = wave_sum(cnt.sph), h = wave_sum(cnt.trih);
+        if (lane == 0 && r != 0ull) {
+            atomicAdd(counter_slot(P, wave_id, 1), b);
+            atomicAdd(counter_slot(P, wave_id, 2), t);
+            atomicAdd(counter_slot(P, wave_id, 3), s);
+            atomicAdd(counter_slot(P, wave_id, 4), h);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Wave-synchronous closest hit.  All lanes of the wave walk the node array together: the wave visits
+// index `cur` when at least one lane's own traversal would visit it.  A lane that fails the slab test
+// of an internal node parks until `cur` reaches that node's skip index (`resume`); because subtrees
+// are nested intervals of the array, no parked lane can want a node before the skip index of a node
+// every active lane has just failed, so the wave's next index is simply cur+1 or skip.  Each lane
+// therefore performs exactly the tests of its own reference traversal, in the same order, with its
+// own running closest distance -- but the node (and triangle / sphere) record is fetched ONCE per
+// wave through the scalar data path into SGPRs instead of 64 times through the vector memory path.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef const v4f __attribute__((address_space(4))) *cf4ptr; // constant address space: scalar loads
+typedef const v8f __attribute__((address_space(4))) *cf8ptr;
+
+// OCT >= 0: every live lane's direction has the same sign pattern (the usual case for the camera rays of
+// a tile).  The near/far plane of each axis is then fixed at compile time instead of chosen by six
+// per-lane selects on the products; "(pNear - o) * inv" is the very product the reference keeps after
+// its swap, so the values are unchanged.
+template <bool OLD, bool STATS, int OCT> // OCT = sign bits (x | y<<1 | z<<2) shared by the wave, or -1 = mixed
+RT_D void wave_walk(const KParams &P, const bool live, const f3 o, const f3 d, const f3 inv, Best &best, Cnt &cnt,
+                    const bool nx, const bool ny, const bool nz) {
+    constexpr bool UNI = OCT >= 0;
+    constexpr bool ux = UNI && (OCT & 1), uy = UNI && (OCT & 2), uz = UNI && (OCT & 4);
+    typedef const char __attribute__((address_space(4))) *cbytes;
+    const cbytes nodes = (cbytes)(uintptr_t)P.nodes;
+    const cf4ptr tri_pos = (cf4ptr)(uintptr_t)P.tri_pos;
+    const cf4ptr spheres = (cf4ptr)(uintptr_t)P.spheres;
+    Best outer = best;
+    uint32_t inner_end = kNone;
+    uint32_t resume = live ? 0u : kNone; // byte offset of the next record this lane takes part in
+    uint32_t cur = 0;                     // byte offset of the wave's current record
+    // The scalar pipe issues one instruction per SIMD every four cycles, so the loop is written to need as
+    // few scalar instructions per node as possible: one 32-byte scalar load, byte offsets instead of indices,
+    // kind word 0 for internal nodes, and no bound check (the array ends with a terminator record).
+    for (;;) {
+        uint32_t skip, kind;
+        float tm, tmin; // kept as floats across the loop exit; flags are re-derived (a carried flag costs selects)
+        // inner loop: internal nodes only (kind word 0) -- the hot part of the walk
+        for (;;) {
+            const v8f r = *(cf8ptr)(nodes + cur);
+            const v4f a = {r[0], r[1], r[2], r[3]}, b = {r[4], r[5], r[6], r[7]};
+            skip = __float_as_uint(b.z);
+            kind = __float_as_uint(b.w);
+            float nearx, farx, neary, fary, nearz, farz;
+            if (UNI) {
+                const float pnx = ux ? a.w : a.x, pfx = ux ? a.x : a.w;
+                const float pny = uy ? b.x : a.y, pfy = uy ? a.y : b.x;
+                const float pnz = uz ? b.y : a.z, pfz = uz ? a.z : b.y;
+                nearx = (pnx - o.x) * inv.x;
+                farx = (pfx - o.x) * inv.x;
+                neary = (pny - o.y) * inv.y;
+                fary = (pfy - o.y) * inv.y;
+                nearz = (pnz - o.z) * inv.z;
+                farz = (pfz - o.z) * inv.z;
+            } else {
+                const float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
+                const float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
+                const float t0z = (a.z - o.z) * inv.z, t1z = (b.y - o.z) * inv.z;
+                nearx = nx ? t1x : t0x;
+                farx = nx ? t0x : t1x;
+                neary = ny ? t1y : t0y;
+                fary = ny ? t0y : t1y;
+                nearz = nz ? t1z : t0z;
+                farz = nz ? t0z : t1z;
+            }
+            const bool act = resume <= cur;
+            if (OLD) {
+                if (act && cur == inner_end) {
+                    if (!(best.t < outer.t))
+                        best = outer;
+                    inner_end = kNone;
+                }
+            }
+            if (STATS)
+                cnt.box += (act && kind != kNone) ? 1ull : 0ull; // the terminator record is not a node
+            // reject iff min(far.., closest) <= max(near.., 1e-6); a NaN plane product drops out of min/max
+            // exactly as it drops out of the reference's "t0 > tMin ? t0 : tMin" selects
+            tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+            tm = fminf(fminf(farz, fminf(fary, farx)), best.t);
+            if (kind != 0u)
+                break;
+            // two ballots of plain comparisons and a scalar AND: cheaper than one ballot of the combined flag
+            const bool anyi = (__builtin_amdgcn_ballot_w64(resume <= cur) & __builtin_amdgcn_ballot_w64(!(tm <= tmin))) != 0ull;
+            resume = ((resume <= cur) & (tm <= tmin)) ? skip : resume;
+            cur = __builtin_amdgcn_readfirstlane(anyi ? cur + 32u : skip);
+        }
+        if (kind == kNone) // terminator record after the last node
+            break;
+        const bool act = resume <= cur;
+        const bool ok = !(tm <= tmin);
+        const bool pass = act & ok;
+        const bool any = (__builtin_amdgcn_ballot_w64(resume <= cur) & __builtin_amdgcn_ballot_w64(!(tm <= tmin))) != 0ull;
+        resume = (act & !ok) ? skip : resume;
+        const uint32_t k = kind & 7u;
+        const uint32_t slot = kind >> 3;
+        uint32_t next = cur + 32u; // == skip for every leaf kind except a mesh leaf nobody entered
+        if (!any) {
+            if (OLD && k == KIND_MESH)
+                next = skip;
+        } else if (k == KIND_TRI) {
+            const v4f q0 = tri_pos[3 * slot], q1 = tri_pos[3 * slot + 1], q2 = tri_pos[3 * slot + 2];
+            if (pass) {
+                if (STATS)
+                    cnt.tri++;
+                const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+                const float EPSILON = 1e-7f;
+                f3 h = cross3(d, e2);
+                float det = dot3(e1, h);
+                if (!(det > -EPSILON && det < EPSILON)) {
+                    float f = 1.0f / det;
+                    f3 sv = o - p0;
+                    float u = f * dot3(sv, h);
+                    if (!(u < 0.0f || u > 1.0f)) {
+                        f3 q = cross3(sv, e1);
+                        float v = f * dot3(d, q);
+                        if (!(v < 0.0f || u + v > 1.0f)) {
+                            float t = f * dot3(e2, q);
+                            if (t > EPSILON && t < best.t) {
+                                best.t = t;
+                                best.u = u;
+                                best.v = v;
+                                best.ref = slot;
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (OLD && k == KIND_SPHERE) {
+            const v4f s0 = spheres[2 * slot], s1 = spheres[2 * slot + 1];
+            if (pass) {
+                if (STATS)
+                    cnt.sph++;
+                f3 oc = mk3(s0.x, s0.y, s0.z) - o;
+                float qa = dot3(d, d);
+                float qb = -2.0f * dot3(d, oc);
+                float qc = dot3(oc, oc) - s0.w * s0.w;
+                float disc = qb * qb - 4 * qa * qc;
+                if (!(disc < 0)) {
+                    float t = (-qb - sqrtf(disc)) / (2.0f * qa);
+                    bool ok = !(t < 0);
+                    if (!ok && __float_as_uint(s1.z) != 0u) {
+                        t = (-qb + sqrtf(disc)) / (2.0f * qa);
+                        ok = !(t < 0);
+                    }
+                    if (ok && t < best.t) {
+                        best.t = t;
+                        best.ref = kSphereBit | slot;
+                    }
+                }
+            }
+        } else if (OLD && k == KIND_MESH) {
+            if (pass) {
+                outer = best;
+                inner_end = skip;
+                best.t = __builtin_inff();
+                best.ref = kNone;
+            }
+        }
+        cur = __builtin_amdgcn_readfirstlane(next);
+    }
+    if (OLD) {
+        if (live && inner_end != kNone) {
+            if (!(best.t < outer.t))
+                best = outer;
+        }
+    }
+}
+
+template <bool OLD, bool STATS>
+RT_D void closest_hit_wave(const KParams &P, const bool live, const f3 o, const f3 d, const f3 inv, Best &best,
+                           Cnt &cnt) {
+    best.t = __builtin_inff();
+    best.u = 0.0f;
+    best.v = 0.0f;
+    best.ref = kNone;
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
+    const unsigned long long mx = __builtin_amdgcn_ballot_w64(live && nx), my = __builtin_amdgcn_ballot_w64(live && ny),
+                             mz = __builtin_amdgcn_ballot_w64(live && nz);
+    const bool uniform = (mx == 0ull || mx == lm) && (my == 0ull || my == lm) && (mz == 0ull || mz == lm);
+    const int oct = uniform ? ((mx != 0ull ? 1 : 0) | (my != 0ull ? 2 : 0) | (mz != 0ull ? 4 : 0)) : -1;
+    switch (oct) {
+    case 0: wave_walk<OLD, STATS, 0>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 1: wave_walk<OLD, STATS, 1>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 2: wave_walk<OLD, STATS, 2>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 3: wave_walk<OLD, STATS, 3>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 4: wave_walk<OLD, STATS, 4>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 5: wave_walk<OLD, STATS, 5>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 6: wave_walk<OLD, STATS, 6>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    case 7: wave_walk<OLD, STATS, 7>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    default: wave_walk<OLD, STATS, -1>(P, live, o, d, inv, best, cnt, nx, ny, nz); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast closest hit: the reference's RESULT without the reference's walk.
+//
+// In the reference traversal (SimplifiedData.cpp:430-462, BVH.hpp:124-148) the interior boxes only prune;
+// every interior box contains the leaf boxes below it, and the slab test is monotone in the box, so a leaf
+// whose own box passes "(1e-6, closest)" has ancestors that passed with the (larger or equal) closest of
+// their moment.  What the reference returns is therefore a function of its LEAVES alone.  Call a leaf a
+// candidate when the ray meets its box at all (slab test with closest = +inf) and its primitive test
+// reports a hit at distance t; let m be the slab test's entry distance max(near planes, 1e-6).  The
+// reference meets the candidates in its fixed visiting order `pos` and accepts one iff closest > m and
+// t < closest.  If the candidate with the smallest (t, pos) has m <= t, it is accepted when its turn comes
+// (everything accepted before it has a larger t) and nothing after it can replace it: it IS the result,
+// whatever happened to the other candidates.  So the walk below visits the device's own tight hierarchy
+// in any order, with no closest-distance pruning at all (a pruned leaf could hide exactly such a
+// candidate), keeps the minimum of (t, pos), and is done unless the winner has m > t -- rounding in a
+// grazing hit, or a sphere that touches its box.  Those rays are resolved by replay_ordered, which plays
+// the reference's acceptance rule over the candidates in `pos` order and needs no more than the fast tree.
+struct Cand {
+    float t, u, v;
+    float m;       // entry distance of the candidate's own leaf box
+    uint32_t ref;  // triangle slot or kSphereBit | sphere index
+    uint32_t pos;  // position of the leaf in the reference's visiting order
+    uint32_t mesh; // OLD: position of the enclosing mesh leaf, kNone for a scene-level primitive
+    float mesh_m;  // OLD: entry distance of that mesh leaf's box
+};
+
+// Position of one lane in the fast tree, for a walk that is taken in several bursts.
+struct Walk {
+    uint32_t idx;       // byte offset of the next record; the walk is over when it reaches the end of the array
+    uint32_t mesh;      // OLD: reference position of the enclosing mesh leaf, kNone outside a mesh
+    uint32_t inner_end; // OLD: byte offset where that mesh's inline hierarchy ends
+    float mesh_m;       // OLD: entry distance of that mesh leaf's box
+};
+
+// BURST = 0: the whole walk.  BURST > 0: at most that many records, resuming from and saving to `w` (the loop itself
+// runs on local copies either way).
+template <bool OLD, bool STATS, int BURST, class F>
+RT_D void fast_walk_from(const KParams &P, const f3 o, const f3 d, const f3 inv, Walk &w, Cnt &cnt, F &&consider) {
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const uint32_t n = P.n_fnodes * 32u;
+    uint32_t idx = w.idx;
+    uint32_t mesh = w.mesh, inner_end = w.inner_end;
+    float mesh_m = w.mesh_m;
+    int budget = BURST;
+    while (idx < n) {
+        if (BURST > 0) {
+            if (budget-- == 0)
+                break;
+        }
+        if (OLD) {
+            if (idx == inner_end) {
+                mesh = kNone;
+                mesh_m = 0.0f;
+                inner_end = kNone;
+            }
+        }
+        const float4 *rec = (const float4 *)((const char *)P.fnodes + idx);
+        const float4 a = rec[0];
+        const float4 b = rec[1];
+        const uint32_t skip = __float_as_uint(b.z);
+        const uint32_t kind = __float_as_uint(b.w);
+        if (STATS)
+            cnt.box++;
+        const float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
+        const float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
+        const float t0z = (a.z - o.z) * inv.z, t1z = (b.y - o.z) * inv.z;
+        const float nearx = nx ? t1x : t0x, farx = nx ? t0x : t1x;
+        const float neary = ny ? t1y : t0y, fary = ny ? t0y : t1y;
+        const float nearz = nz ? t1z : t0z, farz = nz ? t0z : t1z;
+        const float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+        const float tmax = fminf(farz, fminf(fary, fminf(farx, __builtin_inff()))); // the slab test with closest = +inf
+        if (tmax <= tmin) {
+            idx = skip;
+            continue;
+        }
+        idx = idx + 32u;
+        const uint32_t k = kind & 7u;
+        if (k == KIND_INTERNAL)
+            continue;
+        const uint32_t slot = kind >> 3;
+        if (k == KIND_TRI) {
+            if (STATS)
+                cnt.tri++;
+            const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
+            // All nine floats of the triangle are fetched before the test starts: left alone, the compiler sinks the
+            // load of p0 behind the determinant test, which puts a second memory round trip into most triangle tests.
+            asm volatile("" : : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w), "v"(q2.x));
+            const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+            const float EPSILON = 1e-7f;
+            f3 h = cross3(d, e2);
+            float det = dot3(e1, h);
+            if (!(det > -EPSILON && det < EPSILON)) {
+                float f = 1.0f / det;
+                f3 s = o - p0;
+                float u = f * dot3(s, h);
+                if (!(u < 0.0f || u > 1.0f)) {
+                    f3 q = cross3(s, e1);
+                    float v = f * dot3(d, q);
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        float t = f * dot3(e2, q);
+                        if (t > EPSILON)
+                            consider(Cand{t, u, v, tmin, slot, __float_as_uint(q2.w), mesh, mesh_m});
+                    }
+                }
+            }
+        } else if (OLD && k == KIND_SPHERE) {
+            if (STATS)
+                cnt.sph++;
+            const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
+            f3 oc = mk3(s0.x, s0.y, s0.z) - o;
+            float qa = dot3(d, d);
+            float qb = -2.0f * dot3(d, oc);
+            float qc = dot3(oc, oc) - s0.w * s0.w;
+            float disc = qb * qb - 4 * qa * qc;
+            if (!(disc < 0)) {
+                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
+                bool ok = !(t < 0);
+                if (!ok && __float_as_uint(s1.z) != 0u) {
+                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
+                    ok = !(t < 0);
+                }
+                if (ok)
+                    consider(Cand{t, 0.0f, 0.0f, tmin, kSphereBit | slot, __float_as_uint(s1.w), kNone, 0.0f});
+            }
+        } else if (OLD && k == KIND_MESH) { // the mesh's inner hierarchy follows inline, up to `skip`
+            mesh = slot;
+            mesh_m = tmin;
+            inner_end = skip;
+        }
+    }
+    if (BURST > 0) {
+        w.idx = idx;
+        w.mesh = mesh;
+        w.inner_end = inner_end;
+        w.mesh_m = mesh_m;
+    }
+}
+
+template <bool OLD, bool STATS, class F>
+RT_D void fast_walk(const KParams &P, const f3 o, const f3 d, const f3 inv, Cnt &cnt, F &&consider) {
+    Walk w = {0u, kNone, kNone, 0.0f};
+    fast_walk_from<OLD, STATS, 0>(P, o, d, inv, w, cnt, consider);
+}
+
+// Plays the reference's acceptance rule over the candidates in the reference's visiting order.  One pass over
+// the fast tree finds the next candidate the reference would ACCEPT in its current state (between two
+// acceptances the state does not change, so everything in between is skipped for good); the number of passes
+// is the number of acceptances plus one.  A mesh (BVH.hpp:135-137 with Mesh::intersect, Mesh.hpp:154-160)
+// runs its own closest hit from +inf once its scene-level leaf box passes, and hands the result to the scene
+// level when the walk leaves it.
+template <bool OLD, bool STATS>
+RT_D void replay_ordered(const KParams &P, const f3 o, const f3 d, const f3 inv, Best &best, Cnt &cnt) {
+    const float inf = __builtin_inff();
+    float c_out = inf, c_in = inf;
+    Best b_out = {inf, 0.0f, 0.0f, kNone}, b_in = b_out;
+    uint32_t cur_mesh = kNone;
+    uint32_t lo = 0;
+    for (;;) {
+        const float c_after = (OLD && cur_mesh != kNone && c_in < c_out) ? c_in : c_out; // scene-level closest once the current mesh is left
+        Cand f;
+        f.pos = kNone;
+        f.t = inf;
+        f.u = f.v = f.m = f.mesh_m = 0.0f;
+        f.ref = f.mesh = kNone;
+        fast_walk<OLD, STATS>(P, o, d, inv, cnt, [&](const Cand &c) {
+            if (c.pos < lo || c.pos >= f.pos)
+                return;
+            bool ok;
+            if (!OLD || c.mesh == kNone)
+                ok = c_after > c.m && c.t < c_after;
+            else if (c.mesh == cur_mesh)
+                ok = c_in > c.m && c.t < c_in;
+            else
+                ok = c_after > c.mesh_m && c.t < inf; // entering that mesh: its closest starts at +inf
+            if (ok)
+                f = c;
+        });
+        if (f.pos == kNone)
+            break;
+        if (OLD && f.mesh != cur_mesh) {
+            if (cur_mesh != kNone && c_in < c_out) {
+                c_out = c_in;
+                b_out = b_in;
+            }
+            cur_mesh = f.mesh;
+            c_in = inf;
+            b_in.ref = kNone;
+        }
+        if (!OLD || f.mesh == kNone) {
+            c_out = f.t;
+            b_out = Best{f.t, f.u, f.v, f.ref};
+        } else {
+            c_in = f.t;
+            b_in = Best{f.t, f.u, f.v, f.ref};
+        }
+        lo = f.pos + 1u;
+    }
+    if (OLD && cur_mesh != kNone && c_in < c_out)
+        b_out = b_in;
+    best = b_out;
+}
+
+template <bool OLD, bool STATS>
+RT_D void closest_hit_fast(const KParams &P, const f3 o, const f3 d, const f3 inv, Best &best, Cnt &cnt) {
+    best.t = __builtin_inff();
+    best.u = 0.0f;
+    best.v = 0.0f;
+    best.ref = kNone;
+    uint32_t bpos = kNone;
+    float bm = 0.0f;
+    fast_walk<OLD, STATS>(P, o, d, inv, cnt, [&](const Cand &c) {
+        // t = +inf passes the primitive test's "t > EPSILON" but never the reference's "t < closest.t"
+        if ((c.t < best.t || (c.t == best.t && c.pos < bpos)) && c.t < __builtin_inff()) {
+            best = Best{c.t, c.u, c.v, c.ref};
+            bpos = c.pos;
+            bm = fmaxf(c.m, c.mesh_m);
+        }
+    });
+    if (best.ref == kNone) // no candidate: the reference accepts nothing either
+        return;
+    if (bm > best.t || P.force_replay != 0) {
+        cnt.replay++;
+        replay_ordered<OLD, STATS>(P, o, d, inv, best, cnt);
+    }
+}
+
