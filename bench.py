@@ -162,6 +162,11 @@ def main():
     options(False)
     note(f"scene uploaded, work counted ({counts.rays} rays per step)")
 
+    # set-up, untimed like the upload: both of the tracer's internal pipes get their workspace (a step allocates it on
+    # first use), so that the timed region never allocates whatever W is
+    for i in range(2):
+        tr.trace_device(W, H, 1 + i * spp, spp, img.data_ptr())
+    tr.sync()
     render(args.warmup)
     tr.sync()
     note("warm-up done")
