@@ -121,11 +121,13 @@ enum {
     RT_TRAV_REFERENCE = 6, /* reference order; LANE or WAVE chosen from a surface-area estimate of the visits per ray */
     RT_TRAV_FAST_REFILL = 7, /* FAST with lane re-fill (a lane that finishes its walk takes the next ray instead of waiting
                                for its wave); RT_TRAV_FAST itself uses it for scenes larger than the L2s */
-    RT_TRAV_BRUTE = 8        /* "BVH Acceleration" unticked (BVHSettings::toggleBVHAccel, Program/BVHUI.hpp:14,25): no box is
+    RT_TRAV_BRUTE = 8,       /* "BVH Acceleration" unticked (BVHSettings::toggleBVHAccel, Program/BVHUI.hpp:14,25): no box is
                                tested, every primitive is -- Scene::intersectClosest (Program/Scene.hpp:83-95) and the
                                else-branch of Mesh::intersect (CPURayTrace/Mesh.hpp:161-172); for the flat scene, which the
                                reference never traces this way: all triangles in storage order.  A debugging aid: time grows
                                with rays x primitives */
+    RT_TRAV_FAST_QUEUED = 9  /* FAST with the triangle tests taken out of the walk: lanes note them, the wave runs them
+                               together, 64 at a time, once its walks are over */
 };
 
 typedef struct rt_options {

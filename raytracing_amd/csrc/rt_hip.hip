@@ -34,6 +34,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -250,7 +251,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     int trav = o.traversal;
     if (trav == RT_TRAV_AUTO)
         trav = ctx->fast_exact ? RT_TRAV_FAST : RT_TRAV_REFERENCE;
-    if ((trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY || trav == RT_TRAV_FAST_REFILL) && !ctx->fast_exact)
+    if ((trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY || trav == RT_TRAV_FAST_REFILL || trav == RT_TRAV_FAST_QUEUED) && !ctx->fast_exact)
         return fail(ctx, RT_ERR_BAD_SCENE, "RT_TRAV_FAST needs a tree whose interior boxes contain their children's boxes");
     if (trav == RT_TRAV_REFERENCE)
         trav = ctx->expected_visits >= 512.0 ? RT_TRAV_WAVE : RT_TRAV_LANE;
@@ -258,7 +259,11 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     // Lane re-fill pays when walks are long and their fetches miss the L2 (measured: +17 % on the 1.19 M-triangle field,
     // +29 % on the 9.8 M one; -12 % on the 485-sphere scene, neutral on the 18 520-triangle dragon): it is used for
     // scenes whose fast tree and triangle positions exceed the L2s, and when asked for explicitly.
-    const bool refill = trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && ctx->scene_bytes > kRefillSceneBytes);
+    static const bool x_queued = getenv("RT_X_QUEUED") != nullptr && getenv("RT_X_QUEUED")[0] != 0;
+    const bool queued = trav == RT_TRAV_FAST_QUEUED || (trav == RT_TRAV_FAST && x_queued);
+    if (trav == RT_TRAV_FAST_QUEUED)
+        trav = RT_TRAV_FAST;
+    const bool refill = !queued && (trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && ctx->scene_bytes > kRefillSceneBytes));
     if (trav == RT_TRAV_FAST_REFILL)
         trav = RT_TRAV_FAST;
     const int walk = trav == RT_TRAV_WAVE ? WALK_WAVE : (trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY) ? WALK_FAST
@@ -360,7 +365,8 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
             // fetch latency; the spills land in the shading code, which runs once per ray); the others: uncapped
 #define RT_LAUNCH_PATH(OLD_, STATS_)                                                                                  \
     do {                                                                                                              \
-        if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, 0, pp.stream, P);     \
+        if (walk == WALK_FAST && queued) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_QUEUED>), grid, block, 0, pp.stream, P); \
+        else if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, 0, pp.stream, P); \
         else if (walk == WALK_FAST && refill) hipLaunchKernelGGL((k_refill<OLD_, STATS_>), grid, block, 0, pp.stream, P); \
         else if (walk == WALK_FAST) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_FAST>), grid, block, 0, pp.stream, P); \
         else if (walk == WALK_BRUTE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_BRUTE>), grid, block, 0, pp.stream, P); \
@@ -594,7 +600,7 @@ int rt_set_options(rt_ctx *ctx, const rt_options *opt) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (opt->bounce_limit < 0 || opt->bounce_limit > kMaxLevels - 2 || opt->tile_world < 1 || opt->tile_rank < 0 || opt->tile_rank >= opt->tile_world ||
         (opt->estimator != RT_EST_SD_LOOP && opt->estimator != RT_EST_OLD_RECURSIVE) || opt->traversal < 0 ||
-        opt->traversal > RT_TRAV_BRUTE)
+        opt->traversal > RT_TRAV_FAST_QUEUED)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad options");
     ctx->opt = *opt;
     return RT_OK;

@@ -182,10 +182,11 @@ RT_D bool camera_path(const KParams &P, const uint32_t item, Path &path, uint32_
 // full waves, and no lane ever waits for a neighbour's longer path.  The per-sample colours are folded
 // into the running mean afterwards, in sample order, by k_fold, which reproduces the reference's
 // "pixel = (pixel*(n-1) + new)/n" (Renderer/TraceMethods.cpp:59) bit for bit.
-constexpr int WALK_LANE = 0, WALK_WAVE = 1, WALK_FAST = 2, WALK_BRUTE = 3;
+constexpr int WALK_LANE = 0, WALK_WAVE = 1, WALK_FAST = 2, WALK_BRUTE = 3, WALK_QUEUED = 4;
 template <bool OLD, bool STATS, int WALK>
-__global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const KParams P) {
+__global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : (WALK == WALK_QUEUED && !OLD) ? 6 : 1) k_path(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
+    __shared__ WaveJobs s_jobs[WALK == WALK_QUEUED ? 4 : 1]; // only the queued walk touches it
     Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     // Level 0: items are camera rays, batch b = items 64 b .. 64 b + 63.  Deeper levels: the queue is kSubQueues
     // sub-queues, each filled by the level before through its own append counter; lane q of every wave reads count
@@ -290,6 +291,8 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
             cnt.rays++;
         if (WALK == WALK_WAVE && use_wave) {
             closest_hit_wave<OLD, STATS>(P, live, path.o, path.d, path.inv, hit, cnt);
+        } else if (WALK == WALK_QUEUED) {
+            closest_hit_fast_queued<OLD, STATS>(P, live, lane, path.o, path.d, path.inv, hit, cnt, s_jobs[threadIdx.x >> 6]);
         } else {
             hit.ref = kNone;
             hit.t = 0.f;
@@ -347,7 +350,7 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : 1) k_path(const K
             atomicAdd(counter_slot(P, wave_id, 4), h);
         }
     }
-    if (WALK == WALK_FAST) {
+    if (WALK == WALK_FAST || WALK == WALK_QUEUED) {
         unsigned long long rp = wave_sum(cnt.replay);
         if (lane == 0 && rp != 0ull)
             atomicAdd(counter_slot(P, wave_id, 5), rp);

@@ -853,3 +853,207 @@ RT_D void closest_hit_fast(const KParams &P, const f3 o, const f3 d, const f3 in
     }
 }
 
+// closest_hit_fast for a whole wave, with the triangle tests taken OUT of the walk.
+//
+// In the plain walk a lane that stands on a leaf runs the triangle test (four loads, ~60 instructions) while the other
+// lanes of its wave wait, and with dozens of lanes walking some lane stands on a leaf in most steps: a third of a bounce
+// level's time goes into triangle tests that run at a few lanes' worth of use.  Here a lane that passes a leaf box only
+// notes a job -- (its lane, the triangle slot, the box's entry distance) -- in a list the wave keeps in LDS, and walks on.
+// When all lanes have finished their walks the wave runs the noted tests 64 at a time, every lane taking one job whoever
+// noted it: the job's ray comes from its owner's registers (ds_bpermute), a hit goes into the owner's 64-bit LDS word
+// min((t bits << 32) | position) -- t > 0, so the order of the bits is the order of the values -- and the job that holds
+// the minimum afterwards leaves u, v, slot and entry distance for the owner.  The hit kept is the smallest (t, position),
+// as in closest_hit_fast, so the result is the same.  A job that does not fit the list (or a slot beyond 26 bits) is
+// tested on the spot.  Every lane of the wave must call this (lanes without a ray pass live = false and help testing).
+constexpr uint32_t kJobCap = 512;       // jobs a wave can note per closest-hit search of its 64 rays
+constexpr uint32_t kJobSlotBits = 26;
+
+struct WaveJobs {            // LDS of one wave
+    uint2 jobs[kJobCap];     // (owner lane << 26) | slot, entry distance bits
+    unsigned long long key[64];
+    float4 win[64];          // u, v, slot bits, entry distance
+    uint32_t count;
+};
+
+template <bool OLD, bool STATS>
+RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint32_t lane, const f3 o, const f3 d, const f3 inv,
+                                  Best &best, Cnt &cnt, WaveJobs &J) {
+    const float inf = __builtin_inff();
+    best = Best{inf, 0.0f, 0.0f, kNone};
+    uint32_t bpos = kNone;
+    float bm = 0.0f;
+    J.key[lane] = ~0ull;
+    if (lane == 0)
+        J.count = 0u;
+    // ---- the walk: box tests only; triangles are noted ----
+    if (live) {
+        const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+        const uint32_t n = P.n_fnodes * 32u;
+        uint32_t idx = 0u;
+        uint32_t inner_end = kNone;
+        float mesh_m = 0.0f;
+        while (idx < n) {
+            if (OLD) {
+                if (idx == inner_end) {
+                    mesh_m = 0.0f;
+                    inner_end = kNone;
+                }
+            }
+            const float4 *rec = (const float4 *)((const char *)P.fnodes + idx);
+            const float4 a = rec[0];
+            const float4 b = rec[1];
+            const uint32_t skip = __float_as_uint(b.z);
+            const uint32_t kind = __float_as_uint(b.w);
+            if (STATS)
+                cnt.box++;
+            const float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
+            const float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
+            const float t0z = (a.z - o.z) * inv.z, t1z = (b.y - o.z) * inv.z;
+            const float nearx = nx ? t1x : t0x, farx = nx ? t0x : t1x;
+            const float neary = ny ? t1y : t0y, fary = ny ? t0y : t1y;
+            const float nearz = nz ? t1z : t0z, farz = nz ? t0z : t1z;
+            const float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+            const float tmax = fminf(farz, fminf(fary, fminf(farx, inf))); // the slab test with closest = +inf
+            if (tmax <= tmin) {
+                idx = skip;
+                continue;
+            }
+            idx = idx + 32u;
+            const uint32_t k = kind & 7u;
+            if (k == KIND_INTERNAL)
+                continue;
+            const uint32_t slot = kind >> 3;
+            if (k == KIND_TRI) {
+                if (STATS)
+                    cnt.tri++;
+                const float m = OLD ? fmaxf(tmin, mesh_m) : tmin;
+                const uint32_t j = atomicAdd(&J.count, 1u);
+                if (j < kJobCap && slot < (1u << kJobSlotBits)) {
+                    J.jobs[j] = make_uint2((lane << kJobSlotBits) | slot, __float_as_uint(m));
+                } else { // no room: test it here
+                    const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
+                    const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+                    const float EPSILON = 1e-7f;
+                    f3 h = cross3(d, e2);
+                    float det = dot3(e1, h);
+                    if (!(det > -EPSILON && det < EPSILON)) {
+                        float f = 1.0f / det;
+                        f3 s = o - p0;
+                        float u = f * dot3(s, h);
+                        if (!(u < 0.0f || u > 1.0f)) {
+                            f3 q = cross3(s, e1);
+                            float v = f * dot3(d, q);
+                            if (!(v < 0.0f || u + v > 1.0f)) {
+                                float t = f * dot3(e2, q);
+                                const uint32_t pos = __float_as_uint(q2.w);
+                                if (t > EPSILON && (t < best.t || (t == best.t && pos < bpos)) && t < inf) {
+                                    best = Best{t, u, v, slot};
+                                    bpos = pos;
+                                    bm = m;
+                                }
+                            }
+                        }
+                    }
+                }
+            } else if (OLD && k == KIND_SPHERE) {
+                if (STATS)
+                    cnt.sph++;
+                const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
+                f3 oc = mk3(s0.x, s0.y, s0.z) - o;
+                float qa = dot3(d, d);
+                float qb = -2.0f * dot3(d, oc);
+                float qc = dot3(oc, oc) - s0.w * s0.w;
+                float disc = qb * qb - 4 * qa * qc;
+                if (!(disc < 0)) {
+                    float t = (-qb - sqrtf(disc)) / (2.0f * qa);
+                    bool ok = !(t < 0);
+                    if (!ok && __float_as_uint(s1.z) != 0u) {
+                        t = (-qb + sqrtf(disc)) / (2.0f * qa);
+                        ok = !(t < 0);
+                    }
+                    const uint32_t pos = __float_as_uint(s1.w);
+                    if (ok && (t < best.t || (t == best.t && pos < bpos)) && t < inf) {
+                        best = Best{t, 0.0f, 0.0f, kSphereBit | slot};
+                        bpos = pos;
+                        bm = fmaxf(tmin, 0.0f);
+                    }
+                }
+            } else if (OLD && k == KIND_MESH) { // the mesh's inner hierarchy follows inline, up to `skip`
+                mesh_m = tmin;
+                inner_end = skip;
+            }
+        }
+    }
+    // ---- the noted triangle tests, 64 at a time, whoever noted them ----
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t noted = J.count;
+    const uint32_t n_jobs = noted < kJobCap ? noted : kJobCap;
+    for (uint32_t base = 0; base < n_jobs; base += 64u) {
+        const uint32_t j = base + lane;
+        const bool valid = j < n_jobs;
+        const uint2 job = valid ? J.jobs[j] : make_uint2(0u, 0u);
+        const uint32_t owner = job.x >> kJobSlotBits, slot = job.x & ((1u << kJobSlotBits) - 1u);
+        const int sel = (int)(owner << 2);
+        const f3 ro = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.x))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.y))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.z))));
+        const f3 rd = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.x))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.y))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.z))));
+        bool hit = false;
+        unsigned long long key = ~0ull;
+        float hu = 0.0f, hv = 0.0f;
+        if (valid) {
+            const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
+            const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+            const float EPSILON = 1e-7f;
+            f3 h = cross3(rd, e2);
+            float det = dot3(e1, h);
+            if (!(det > -EPSILON && det < EPSILON)) {
+                float f = 1.0f / det;
+                f3 s = ro - p0;
+                float u = f * dot3(s, h);
+                if (!(u < 0.0f || u > 1.0f)) {
+                    f3 q = cross3(s, e1);
+                    float v = f * dot3(rd, q);
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        float t = f * dot3(e2, q);
+                        // t = +inf passes "t > EPSILON" but never the reference's "t < closest.t"
+                        if (t > EPSILON && t < inf) {
+                            hit = true;
+                            key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)__float_as_uint(q2.w);
+                            hu = u;
+                            hv = v;
+                        }
+                    }
+                }
+            }
+        }
+        if (hit)
+            atomicMin(&J.key[owner], key);
+        __builtin_amdgcn_wave_barrier();
+        if (hit) {
+            if (J.key[owner] == key)
+                J.win[owner] = make_float4(hu, hv, __uint_as_float(slot), __uint_as_float(job.y));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const unsigned long long mine = J.key[lane];
+    if (live && mine != ~0ull) {
+        const float t = __uint_as_float((uint32_t)(mine >> 32));
+        const uint32_t pos = (uint32_t)mine;
+        if (t < best.t || (t == best.t && pos < bpos)) {
+            const float4 wv = J.win[lane];
+            best = Best{t, wv.x, wv.y, __float_as_uint(wv.z)};
+            bpos = pos;
+            bm = wv.w;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (live && best.ref != kNone && (bm > best.t || P.force_replay != 0)) {
+        cnt.replay++;
+        replay_ordered<OLD, STATS>(P, o, d, inv, best, cnt);
+    }
+}
+
+

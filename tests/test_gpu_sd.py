@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 # per-lane walk, the first-generation nested-loop kernel (these three perform the reference's own tests, so
 # their test counts equal the oracle's too), the fast walk over the device's own hierarchy, and the fast
 # walk with every ray forced through its ordered replay
-TRAVS = [R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED, R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL]
+TRAVS = [R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED, R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED]
 REFERENCE_ORDER = (R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED)
 
 
@@ -189,13 +189,15 @@ def test_full_size_properties_fast_vs_reference_order(tracer):
     tracer.upload(ps)
     tracer.set_camera(WL.DRAGON_18520_CAMERA)
     out = {}
-    for trav in (R.TRAV_FAST, R.TRAV_WAVE):
+    for trav in (R.TRAV_FAST, R.TRAV_FAST_QUEUED, R.TRAV_WAVE):
         tracer.set_options(bounce_limit=8, seed=1, traversal=trav)
         out[trav] = tracer.trace(1920, 1080, 1, 2, want_primary=True)
-    (fi, fp, fs), (wi, wp, ws) = out[R.TRAV_FAST], out[R.TRAV_WAVE]
-    assert fs.rays == ws.rays
-    assert np.array_equal(fp, wp)
-    assert np.array_equal(bits(fi), bits(wi))
+    fi, fp, fs = out[R.TRAV_FAST]
+    for trav in (R.TRAV_FAST_QUEUED, R.TRAV_WAVE):
+        wi, wp, ws = out[trav]
+        assert fs.rays == ws.rays
+        assert np.array_equal(fp, wp)
+        assert np.array_equal(bits(fi), bits(wi))
     # alpha = fraction of samples that escaped to the sky, in [0, 1]; colours are finite and non-negative
     assert np.isfinite(fi).all() and fi.min() >= 0.0 and fi[..., 3].max() <= 1.0
 
