@@ -866,12 +866,14 @@ RT_D void closest_hit_fast(const KParams &P, const f3 o, const f3 d, const f3 in
 // as in closest_hit_fast, so the result is the same.  A job that does not fit the list (or a slot beyond 26 bits) is
 // tested on the spot.  Every lane of the wave must call this (lanes without a ray pass live = false and help testing).
 constexpr uint32_t kJobCap = 512;       // jobs a wave can note per closest-hit search of its 64 rays
-constexpr uint32_t kJobSlotBits = 26;
+constexpr uint32_t kJobSlotBits = 26;     // a job's first word: owner lane (6 bits), sphere flag (bit 25), slot (25 bits)
+constexpr uint32_t kJobSphere = 1u << 25;
 
 struct WaveJobs {            // LDS of one wave
     uint2 jobs[kJobCap];     // (owner lane << 26) | slot, entry distance bits
     unsigned long long key[64];
-    float4 win[64];          // u, v, slot bits, entry distance
+    float4 win[64];          // u, v, hit reference (Best::ref), entry distance
+    float win_t[64];         // the hit distance itself (the key holds +0 for -0)
     uint32_t count;
 };
 
@@ -928,7 +930,7 @@ RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint3
                     cnt.tri++;
                 const float m = OLD ? fmaxf(tmin, mesh_m) : tmin;
                 const uint32_t j = atomicAdd(&J.count, 1u);
-                if (j < kJobCap && slot < (1u << kJobSlotBits)) {
+                if (j < kJobCap && slot < kJobSphere) {
                     J.jobs[j] = make_uint2((lane << kJobSlotBits) | slot, __float_as_uint(m));
                 } else { // no room: test it here
                     const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
@@ -958,24 +960,29 @@ RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint3
             } else if (OLD && k == KIND_SPHERE) {
                 if (STATS)
                     cnt.sph++;
-                const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
-                f3 oc = mk3(s0.x, s0.y, s0.z) - o;
-                float qa = dot3(d, d);
-                float qb = -2.0f * dot3(d, oc);
-                float qc = dot3(oc, oc) - s0.w * s0.w;
-                float disc = qb * qb - 4 * qa * qc;
-                if (!(disc < 0)) {
-                    float t = (-qb - sqrtf(disc)) / (2.0f * qa);
-                    bool ok = !(t < 0);
-                    if (!ok && __float_as_uint(s1.z) != 0u) {
-                        t = (-qb + sqrtf(disc)) / (2.0f * qa);
-                        ok = !(t < 0);
-                    }
-                    const uint32_t pos = __float_as_uint(s1.w);
-                    if (ok && (t < best.t || (t == best.t && pos < bpos)) && t < inf) {
-                        best = Best{t, 0.0f, 0.0f, kSphereBit | slot};
-                        bpos = pos;
-                        bm = fmaxf(tmin, 0.0f);
+                const uint32_t j = atomicAdd(&J.count, 1u);
+                if (j < kJobCap && slot < kJobSphere) {
+                    J.jobs[j] = make_uint2((lane << kJobSlotBits) | kJobSphere | slot, __float_as_uint(fmaxf(tmin, 0.0f)));
+                } else { // no room: test it here
+                    const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
+                    f3 oc = mk3(s0.x, s0.y, s0.z) - o;
+                    float qa = dot3(d, d);
+                    float qb = -2.0f * dot3(d, oc);
+                    float qc = dot3(oc, oc) - s0.w * s0.w;
+                    float disc = qb * qb - 4 * qa * qc;
+                    if (!(disc < 0)) {
+                        float t = (-qb - sqrtf(disc)) / (2.0f * qa);
+                        bool ok = !(t < 0);
+                        if (!ok && __float_as_uint(s1.z) != 0u) {
+                            t = (-qb + sqrtf(disc)) / (2.0f * qa);
+                            ok = !(t < 0);
+                        }
+                        const uint32_t pos = __float_as_uint(s1.w);
+                        if (ok && (t < best.t || (t == best.t && pos < bpos)) && t < inf) {
+                            best = Best{t, 0.0f, 0.0f, kSphereBit | slot};
+                            bpos = pos;
+                            bm = fmaxf(tmin, 0.0f);
+                        }
                     }
                 }
             } else if (OLD && k == KIND_MESH) { // the mesh's inner hierarchy follows inline, up to `skip`
@@ -992,7 +999,8 @@ RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint3
         const uint32_t j = base + lane;
         const bool valid = j < n_jobs;
         const uint2 job = valid ? J.jobs[j] : make_uint2(0u, 0u);
-        const uint32_t owner = job.x >> kJobSlotBits, slot = job.x & ((1u << kJobSlotBits) - 1u);
+        const uint32_t owner = job.x >> kJobSlotBits, slot = job.x & (kJobSphere - 1u);
+        const bool sphere = OLD && (job.x & kJobSphere) != 0u;
         const int sel = (int)(owner << 2);
         const f3 ro = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.x))),
                           __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.y))),
@@ -1002,8 +1010,30 @@ RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint3
                           __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.z))));
         bool hit = false;
         unsigned long long key = ~0ull;
-        float hu = 0.0f, hv = 0.0f;
-        if (valid) {
+        float hu = 0.0f, hv = 0.0f, ht = 0.0f;
+        uint32_t href = slot;
+        if (valid && sphere) {
+            const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
+            f3 oc = mk3(s0.x, s0.y, s0.z) - ro;
+            float qa = dot3(rd, rd);
+            float qb = -2.0f * dot3(rd, oc);
+            float qc = dot3(oc, oc) - s0.w * s0.w;
+            float disc = qb * qb - 4 * qa * qc;
+            if (!(disc < 0)) {
+                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
+                bool ok = !(t < 0);
+                if (!ok && __float_as_uint(s1.z) != 0u) {
+                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
+                    ok = !(t < 0);
+                }
+                if (ok && t < inf) { // t >= 0 here (NaN fails "t < inf"); -0 takes the key of +0, which it equals
+                    hit = true;
+                    key = ((unsigned long long)(t == 0.0f ? 0u : __float_as_uint(t)) << 32) | (unsigned long long)__float_as_uint(s1.w);
+                    ht = t;
+                    href = kSphereBit | slot;
+                }
+            }
+        } else if (valid) {
             const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
             const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
             const float EPSILON = 1e-7f;
@@ -1024,6 +1054,7 @@ RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint3
                             key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)__float_as_uint(q2.w);
                             hu = u;
                             hv = v;
+                            ht = t;
                         }
                     }
                 }
@@ -1033,14 +1064,16 @@ RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint3
             atomicMin(&J.key[owner], key);
         __builtin_amdgcn_wave_barrier();
         if (hit) {
-            if (J.key[owner] == key)
-                J.win[owner] = make_float4(hu, hv, __uint_as_float(slot), __uint_as_float(job.y));
+            if (J.key[owner] == key) {
+                J.win[owner] = make_float4(hu, hv, __uint_as_float(href), __uint_as_float(job.y));
+                J.win_t[owner] = ht;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
     const unsigned long long mine = J.key[lane];
     if (live && mine != ~0ull) {
-        const float t = __uint_as_float((uint32_t)(mine >> 32));
+        const float t = J.win_t[lane];
         const uint32_t pos = (uint32_t)mine;
         if (t < best.t || (t == best.t && pos < bpos)) {
             const float4 wv = J.win[lane];
