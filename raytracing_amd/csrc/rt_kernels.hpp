@@ -374,6 +374,13 @@ template <bool OLD, bool STATS>
 __global__ void __launch_bounds__(256) k_refill(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
+    // Primitive tests are taken out of the walk as in closest_hit_fast_queued: lanes note them, the wave runs them together
+    // before it shades (and whenever its list is about to fill up).
+    __shared__ WaveJobs s_jobs[4];
+    WaveJobs &J = s_jobs[threadIdx.x >> 6];
+    J.key[lane] = ~0ull;
+    if (lane == 0)
+        J.count = 0u;
     Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     uint32_t sub_count = 0u, sub_end = 0u;
     uint32_t n_batches;
@@ -420,6 +427,7 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
         best = Best{__builtin_inff(), 0.0f, 0.0f, kNone};
         bpos = kNone;
         bm = 0.0f;
+        J.key[lane] = ~0ull;
         cnt.rays++;
     };
     for (;;) {
@@ -478,8 +486,17 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
                         bpos = c.pos;
                         bm = fmaxf(c.m, c.mesh_m);
                     }
+                }, [&](const uint32_t sphere, const uint32_t slot, const float m) -> bool {
+                    const uint32_t j = atomicAdd(&J.count, 1u);
+                    if (!(j < kJobCap && slot < kJobSphere))
+                        return false; // no room: the walk runs the test itself
+                    J.jobs[j] = make_uint2((lane << kJobSlotBits) | (sphere != 0u ? kJobSphere : 0u) | slot, __float_as_uint(m));
+                    return true;
                 });
             }
+            __builtin_amdgcn_wave_barrier();
+            if (J.count + 64u * (uint32_t)kBurst / 4u > kJobCap) // the next burst could overflow the list: run what is noted
+                resolve_jobs<OLD>(P, lane, path.o, path.d, J);
             const unsigned long long walking = __ballot(has && w.idx < n);
             if (walking == 0ull)
                 break;
@@ -489,6 +506,8 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
                 break;
         }
         // ---- shade the finished walks ----
+        resolve_jobs<OLD>(P, lane, path.o, path.d, J);
+        take_noted_result(has && !(w.idx < n), lane, J, best, bpos, bm);
         bool cont = false;
         if (has && !(w.idx < n)) {
             if (best.ref != kNone && (bm > best.t || P.force_replay != 0)) { // see closest_hit_fast

@@ -663,8 +663,13 @@ struct Walk {
 
 // BURST = 0: the whole walk.  BURST > 0: at most that many records, resuming from and saving to `w` (the loop itself
 // runs on local copies either way).
-template <bool OLD, bool STATS, int BURST, class F>
-RT_D void fast_walk_from(const KParams &P, const f3 o, const f3 d, const f3 inv, Walk &w, Cnt &cnt, F &&consider) {
+// `note(is_sphere, slot, entry distance)` may take a primitive test off the walk's hands (it returns true and the caller
+// runs the test later, see WaveJobs); the default takes none.
+struct NotesNothing {
+    RT_D bool operator()(uint32_t, uint32_t, float) const { return false; }
+};
+template <bool OLD, bool STATS, int BURST, class F, class N = NotesNothing>
+RT_D void fast_walk_from(const KParams &P, const f3 o, const f3 d, const f3 inv, Walk &w, Cnt &cnt, F &&consider, N &&note = N()) {
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     const uint32_t n = P.n_fnodes * 32u;
     uint32_t idx = w.idx;
@@ -710,6 +715,8 @@ RT_D void fast_walk_from(const KParams &P, const f3 o, const f3 d, const f3 inv,
         if (k == KIND_TRI) {
             if (STATS)
                 cnt.tri++;
+            if (note(0u, slot, OLD ? fmaxf(tmin, mesh_m) : tmin))
+                continue;
             const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
             // All nine floats of the triangle are fetched before the test starts: left alone, the compiler sinks the
             // load of p0 behind the determinant test, which puts a second memory round trip into most triangle tests.
@@ -735,6 +742,8 @@ RT_D void fast_walk_from(const KParams &P, const f3 o, const f3 d, const f3 inv,
         } else if (OLD && k == KIND_SPHERE) {
             if (STATS)
                 cnt.sph++;
+            if (note(1u, slot, fmaxf(tmin, 0.0f)))
+                continue;
             const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
             f3 oc = mk3(s0.x, s0.y, s0.z) - o;
             float qa = dot3(d, d);
@@ -877,6 +886,111 @@ struct WaveJobs {            // LDS of one wave
     uint32_t count;
 };
 
+// Runs the tests a wave has noted, 64 at a time, whoever noted them, and leaves each owner's best in J.key / J.win /
+// J.win_t.  `o`, `d`: this lane's own ray (a job's ray is fetched from its owner's registers).  Every lane of the wave
+// must call this; the list is empty afterwards.
+template <bool OLD>
+RT_D void resolve_jobs(const KParams &P, const uint32_t lane, const f3 o, const f3 d, WaveJobs &J) {
+    const float inf = __builtin_inff();
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t noted = J.count;
+    const uint32_t n_jobs = noted < kJobCap ? noted : kJobCap;
+    for (uint32_t base = 0; base < n_jobs; base += 64u) {
+        const uint32_t j = base + lane;
+        const bool valid = j < n_jobs;
+        const uint2 job = valid ? J.jobs[j] : make_uint2(0u, 0u);
+        const uint32_t owner = job.x >> kJobSlotBits, slot = job.x & (kJobSphere - 1u);
+        const bool sphere = OLD && (job.x & kJobSphere) != 0u;
+        const int sel = (int)(owner << 2);
+        const f3 ro = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.x))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.y))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.z))));
+        const f3 rd = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.x))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.y))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.z))));
+        bool hit = false;
+        unsigned long long key = ~0ull;
+        float hu = 0.0f, hv = 0.0f, ht = 0.0f;
+        uint32_t href = slot;
+        if (valid && sphere) {
+            const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
+            f3 oc = mk3(s0.x, s0.y, s0.z) - ro;
+            float qa = dot3(rd, rd);
+            float qb = -2.0f * dot3(rd, oc);
+            float qc = dot3(oc, oc) - s0.w * s0.w;
+            float disc = qb * qb - 4 * qa * qc;
+            if (!(disc < 0)) {
+                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
+                bool ok = !(t < 0);
+                if (!ok && __float_as_uint(s1.z) != 0u) {
+                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
+                    ok = !(t < 0);
+                }
+                if (ok && t < inf) { // t >= 0 here (NaN fails "t < inf"); -0 takes the key of +0, which it equals
+                    hit = true;
+                    key = ((unsigned long long)(t == 0.0f ? 0u : __float_as_uint(t)) << 32) | (unsigned long long)__float_as_uint(s1.w);
+                    ht = t;
+                    href = kSphereBit | slot;
+                }
+            }
+        } else if (valid) {
+            const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
+            const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+            const float EPSILON = 1e-7f;
+            f3 h = cross3(rd, e2);
+            float det = dot3(e1, h);
+            if (!(det > -EPSILON && det < EPSILON)) {
+                float f = 1.0f / det;
+                f3 s = ro - p0;
+                float u = f * dot3(s, h);
+                if (!(u < 0.0f || u > 1.0f)) {
+                    f3 q = cross3(s, e1);
+                    float v = f * dot3(rd, q);
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        float t = f * dot3(e2, q);
+                        // t = +inf passes "t > EPSILON" but never the reference's "t < closest.t"
+                        if (t > EPSILON && t < inf) {
+                            hit = true;
+                            key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)__float_as_uint(q2.w);
+                            hu = u;
+                            hv = v;
+                            ht = t;
+                        }
+                    }
+                }
+            }
+        }
+        if (hit)
+            atomicMin(&J.key[owner], key);
+        __builtin_amdgcn_wave_barrier();
+        if (hit) {
+            if (J.key[owner] == key) {
+                J.win[owner] = make_float4(hu, hv, __uint_as_float(href), __uint_as_float(job.y));
+                J.win_t[owner] = ht;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0)
+        J.count = 0u;
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Merges what resolve_jobs left for this lane into the lane's own best (which holds the tests it ran on the spot).
+RT_D void take_noted_result(const bool live, const uint32_t lane, WaveJobs &J, Best &best, uint32_t &bpos, float &bm) {
+    const unsigned long long mine = J.key[lane];
+    if (live && mine != ~0ull) {
+        const float t = J.win_t[lane];
+        const uint32_t pos = (uint32_t)mine;
+        if (t < best.t || (t == best.t && pos < bpos)) {
+            const float4 wv = J.win[lane];
+            best = Best{t, wv.x, wv.y, __float_as_uint(wv.z)};
+            bpos = pos;
+            bm = wv.w;
+        }
+    }
+}
+
 template <bool OLD, bool STATS>
 RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint32_t lane, const f3 o, const f3 d, const f3 inv,
                                   Best &best, Cnt &cnt, WaveJobs &J) {
@@ -991,97 +1105,8 @@ RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint3
             }
         }
     }
-    // ---- the noted triangle tests, 64 at a time, whoever noted them ----
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t noted = J.count;
-    const uint32_t n_jobs = noted < kJobCap ? noted : kJobCap;
-    for (uint32_t base = 0; base < n_jobs; base += 64u) {
-        const uint32_t j = base + lane;
-        const bool valid = j < n_jobs;
-        const uint2 job = valid ? J.jobs[j] : make_uint2(0u, 0u);
-        const uint32_t owner = job.x >> kJobSlotBits, slot = job.x & (kJobSphere - 1u);
-        const bool sphere = OLD && (job.x & kJobSphere) != 0u;
-        const int sel = (int)(owner << 2);
-        const f3 ro = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.x))),
-                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.y))),
-                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.z))));
-        const f3 rd = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.x))),
-                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.y))),
-                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.z))));
-        bool hit = false;
-        unsigned long long key = ~0ull;
-        float hu = 0.0f, hv = 0.0f, ht = 0.0f;
-        uint32_t href = slot;
-        if (valid && sphere) {
-            const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
-            f3 oc = mk3(s0.x, s0.y, s0.z) - ro;
-            float qa = dot3(rd, rd);
-            float qb = -2.0f * dot3(rd, oc);
-            float qc = dot3(oc, oc) - s0.w * s0.w;
-            float disc = qb * qb - 4 * qa * qc;
-            if (!(disc < 0)) {
-                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
-                bool ok = !(t < 0);
-                if (!ok && __float_as_uint(s1.z) != 0u) {
-                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
-                    ok = !(t < 0);
-                }
-                if (ok && t < inf) { // t >= 0 here (NaN fails "t < inf"); -0 takes the key of +0, which it equals
-                    hit = true;
-                    key = ((unsigned long long)(t == 0.0f ? 0u : __float_as_uint(t)) << 32) | (unsigned long long)__float_as_uint(s1.w);
-                    ht = t;
-                    href = kSphereBit | slot;
-                }
-            }
-        } else if (valid) {
-            const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
-            const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
-            const float EPSILON = 1e-7f;
-            f3 h = cross3(rd, e2);
-            float det = dot3(e1, h);
-            if (!(det > -EPSILON && det < EPSILON)) {
-                float f = 1.0f / det;
-                f3 s = ro - p0;
-                float u = f * dot3(s, h);
-                if (!(u < 0.0f || u > 1.0f)) {
-                    f3 q = cross3(s, e1);
-                    float v = f * dot3(rd, q);
-                    if (!(v < 0.0f || u + v > 1.0f)) {
-                        float t = f * dot3(e2, q);
-                        // t = +inf passes "t > EPSILON" but never the reference's "t < closest.t"
-                        if (t > EPSILON && t < inf) {
-                            hit = true;
-                            key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)__float_as_uint(q2.w);
-                            hu = u;
-                            hv = v;
-                            ht = t;
-                        }
-                    }
-                }
-            }
-        }
-        if (hit)
-            atomicMin(&J.key[owner], key);
-        __builtin_amdgcn_wave_barrier();
-        if (hit) {
-            if (J.key[owner] == key) {
-                J.win[owner] = make_float4(hu, hv, __uint_as_float(href), __uint_as_float(job.y));
-                J.win_t[owner] = ht;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    const unsigned long long mine = J.key[lane];
-    if (live && mine != ~0ull) {
-        const float t = J.win_t[lane];
-        const uint32_t pos = (uint32_t)mine;
-        if (t < best.t || (t == best.t && pos < bpos)) {
-            const float4 wv = J.win[lane];
-            best = Best{t, wv.x, wv.y, __float_as_uint(wv.z)};
-            bpos = pos;
-            bm = wv.w;
-        }
-    }
+    resolve_jobs<OLD>(P, lane, o, d, J);
+    take_noted_result(live, lane, J, best, bpos, bm);
     __builtin_amdgcn_wave_barrier();
     if (live && best.ref != kNone && (bm > best.t || P.force_replay != 0)) {
         cnt.replay++;
