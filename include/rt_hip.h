@@ -106,9 +106,10 @@ enum {
  *   order over the reference's node boxes; they differ only in how node records are fetched.
  *   FAST derives the same result from the reference's LEAF boxes alone, walking a surface-area-heuristic
  *   hierarchy of exact unions the upload builds above them (see rt_upload_scene); it does far fewer tests
- *   when the reference's interior boxes prune badly.  FAST_REPLAY forces every ray through FAST's ordered
- *   replay procedure, which normally resolves only rays whose winning hit lies in front of its own leaf
- *   box's entry distance (a verification aid). */
+ *   when the reference's interior boxes prune badly.  The library picks how the walk is run: FAST_QUEUED for
+ *   scenes that fit the L2s, FAST_REFILL beyond; FAST_INLINE is the plain form.  FAST_REPLAY forces every ray
+ *   through FAST's ordered replay procedure, which normally resolves only rays whose winning hit lies in front of
+ *   its own leaf box's entry distance (a verification aid). */
 enum {
     RT_TRAV_AUTO = 0,      /* = RT_TRAV_FAST; = RT_TRAV_REFERENCE for an uploaded tree in which some interior box does not
                               contain its children's boxes (the reference's builders never produce one; FAST is exact
@@ -120,14 +121,16 @@ enum {
     RT_TRAV_FAST_REPLAY = 5,
     RT_TRAV_REFERENCE = 6, /* reference order; LANE or WAVE chosen from a surface-area estimate of the visits per ray */
     RT_TRAV_FAST_REFILL = 7, /* FAST with lane re-fill (a lane that finishes its walk takes the next ray instead of waiting
-                               for its wave); RT_TRAV_FAST itself uses it for scenes larger than the L2s */
+                               for its wave) and noted primitive tests; RT_TRAV_FAST itself uses it for scenes larger than
+                               the L2s */
     RT_TRAV_BRUTE = 8,       /* "BVH Acceleration" unticked (BVHSettings::toggleBVHAccel, Program/BVHUI.hpp:14,25): no box is
                                tested, every primitive is -- Scene::intersectClosest (Program/Scene.hpp:83-95) and the
                                else-branch of Mesh::intersect (CPURayTrace/Mesh.hpp:161-172); for the flat scene, which the
                                reference never traces this way: all triangles in storage order.  A debugging aid: time grows
                                with rays x primitives */
-    RT_TRAV_FAST_QUEUED = 9  /* FAST with the triangle tests taken out of the walk: lanes note them, the wave runs them
-                               together, 64 at a time, once its walks are over */
+    RT_TRAV_FAST_QUEUED = 9, /* FAST with the primitive tests taken out of the walk: lanes note them, the wave runs them
+                               together, 64 at a time, once its walks are over; RT_TRAV_FAST itself for scenes within the L2s */
+    RT_TRAV_FAST_INLINE = 10 /* FAST with every primitive test run where the walk meets it */
 };
 
 typedef struct rt_options {

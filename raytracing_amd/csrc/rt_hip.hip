@@ -34,7 +34,6 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -251,19 +250,17 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     int trav = o.traversal;
     if (trav == RT_TRAV_AUTO)
         trav = ctx->fast_exact ? RT_TRAV_FAST : RT_TRAV_REFERENCE;
-    if ((trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY || trav == RT_TRAV_FAST_REFILL || trav == RT_TRAV_FAST_QUEUED) && !ctx->fast_exact)
+    if ((trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY || trav == RT_TRAV_FAST_REFILL || trav == RT_TRAV_FAST_QUEUED || trav == RT_TRAV_FAST_INLINE) && !ctx->fast_exact)
         return fail(ctx, RT_ERR_BAD_SCENE, "RT_TRAV_FAST needs a tree whose interior boxes contain their children's boxes");
     if (trav == RT_TRAV_REFERENCE)
         trav = ctx->expected_visits >= 512.0 ? RT_TRAV_WAVE : RT_TRAV_LANE;
     P.force_replay = trav == RT_TRAV_FAST_REPLAY ? 1 : 0;
-    // Lane re-fill pays when walks are long and their fetches miss the L2 (measured: +17 % on the 1.19 M-triangle field,
-    // +29 % on the 9.8 M one; -12 % on the 485-sphere scene, neutral on the 18 520-triangle dragon): it is used for
-    // scenes whose fast tree and triangle positions exceed the L2s, and when asked for explicitly.
-    static const bool x_queued = getenv("RT_X_QUEUED") != nullptr && getenv("RT_X_QUEUED")[0] != 0;
-    const bool queued = trav == RT_TRAV_FAST_QUEUED || (trav == RT_TRAV_FAST && x_queued);
-    if (trav == RT_TRAV_FAST_QUEUED)
+    // RT_TRAV_FAST: lane re-fill pays when walks are long and their fetches miss the L2 -- scenes whose fast tree and
+    // triangle positions exceed the L2s; smaller scenes take k_path with the noted primitive tests.
+    const bool refill = trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && ctx->scene_bytes > kRefillSceneBytes);
+    const bool queued = trav == RT_TRAV_FAST_QUEUED || (trav == RT_TRAV_FAST && !refill);
+    if (trav == RT_TRAV_FAST_QUEUED || trav == RT_TRAV_FAST_INLINE)
         trav = RT_TRAV_FAST;
-    const bool refill = !queued && (trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && ctx->scene_bytes > kRefillSceneBytes));
     if (trav == RT_TRAV_FAST_REFILL)
         trav = RT_TRAV_FAST;
     const int walk = trav == RT_TRAV_WAVE ? WALK_WAVE : (trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY) ? WALK_FAST
@@ -600,7 +597,7 @@ int rt_set_options(rt_ctx *ctx, const rt_options *opt) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (opt->bounce_limit < 0 || opt->bounce_limit > kMaxLevels - 2 || opt->tile_world < 1 || opt->tile_rank < 0 || opt->tile_rank >= opt->tile_world ||
         (opt->estimator != RT_EST_SD_LOOP && opt->estimator != RT_EST_OLD_RECURSIVE) || opt->traversal < 0 ||
-        opt->traversal > RT_TRAV_FAST_QUEUED)
+        opt->traversal > RT_TRAV_FAST_INLINE)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad options");
     ctx->opt = *opt;
     return RT_OK;

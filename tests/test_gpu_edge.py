@@ -10,7 +10,7 @@ from helpers import O, R, WL, bits, objparse, oracle_camera
 
 pytestmark = pytest.mark.gpu
 
-TRAVS = [R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_LANE, R.TRAV_WAVE, R.TRAV_NESTED]
+TRAVS = [R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE, R.TRAV_LANE, R.TRAV_WAVE, R.TRAV_NESTED]
 
 
 @pytest.fixture(scope="module")
@@ -203,3 +203,26 @@ def test_camera_a_hair_above_the_surface(tracer):
         _, _, st = tracer.trace(64, 36, 1, 2)
         replays += st.replays
     assert replays > 100
+
+
+def test_more_noted_tests_than_a_wave_can_hold(tracer):
+    """Forty big triangles stacked behind each other, each a leaf whose box every camera ray passes: a wave of 64 rays
+    meets 2 560 leaves per search, five times what its list of noted primitive tests holds (512), so most tests take the
+    run-on-the-spot path of the queued and re-fill walks while the rest go through the list -- same bits either way.  A
+    second model of small triangles in front makes the closest hit come sometimes from the list, sometimes from the spot."""
+    rng = np.random.default_rng(11)
+    big = []
+    for k in range(40):
+        z = -2.0 - 0.05 * k
+        big.append(tri((-6.0, -4.0, z), (6.0, -4.0, z + 0.01 * (k % 3)), (0.0, 6.0, z)))
+    small = []
+    for _ in range(300):
+        c = rng.uniform(-1.5, 1.5, size=3) * np.array([1.0, 0.7, 0.3]) + np.array([0.0, 0.0, -1.2])
+        a, b2 = rng.normal(size=3) * 0.12, rng.normal(size=3) * 0.12
+        nrm = np.cross(a, b2)
+        nrm = nrm / (np.linalg.norm(nrm) + 1e-12)
+        small.append(tri(c, c + a, c + b2, tuple(nrm)))
+    ps, os_ = both_scenes([np.array(big), np.array(small)])
+    cam = R.Camera(1.0, (0.0, 0.0, 1.0), 2.0, 16.0 / 9.0, (0.0, 0.0, -2.0))
+    prim = compare(tracer, ps, os_, cam, 160, 90, spp=3, min_hits=160 * 90 // 2)
+    assert len(np.unique(prim)) > 40
