@@ -130,7 +130,9 @@ enum {
                                with rays x primitives */
     RT_TRAV_FAST_QUEUED = 9, /* FAST with the primitive tests taken out of the walk: lanes note them, the wave runs them
                                together, 64 at a time, once its walks are over; RT_TRAV_FAST itself for scenes within the L2s */
-    RT_TRAV_FAST_INLINE = 10 /* FAST with every primitive test run where the walk meets it */
+    RT_TRAV_FAST_INLINE = 10, /* FAST with every primitive test run where the walk meets it */
+    RT_TRAV_FAST_SLICED = 11  /* FAST in slices: a launch takes every ray a bounded number of records further and hands
+                                 unfinished walks, with their state, to the next launch; primitive tests noted */
 };
 
 typedef struct rt_options {

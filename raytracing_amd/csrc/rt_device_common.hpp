@@ -46,6 +46,8 @@ struct KParams {
     uint32_t n_nodes;
     uint32_t n_fnodes;
     int tail;         // k_path: the last level (follow every path to its end; nothing is queued)
+    uint32_t slice;   // k_sliced: records a ray is taken further per round
+    uint32_t tail_rays; // k_sliced: a round with no more rays than this finishes every path in place
     int force_replay; // fast walk: resolve every ray by the ordered replay (verification aid)
     uint32_t n_my_tiles;
     int W, H, tiles_x;

@@ -34,6 +34,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -250,7 +251,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     int trav = o.traversal;
     if (trav == RT_TRAV_AUTO)
         trav = ctx->fast_exact ? RT_TRAV_FAST : RT_TRAV_REFERENCE;
-    if ((trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY || trav == RT_TRAV_FAST_REFILL || trav == RT_TRAV_FAST_QUEUED || trav == RT_TRAV_FAST_INLINE) && !ctx->fast_exact)
+    if ((trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY || trav == RT_TRAV_FAST_REFILL || trav == RT_TRAV_FAST_QUEUED || trav == RT_TRAV_FAST_INLINE || trav == RT_TRAV_FAST_SLICED) && !ctx->fast_exact)
         return fail(ctx, RT_ERR_BAD_SCENE, "RT_TRAV_FAST needs a tree whose interior boxes contain their children's boxes");
     if (trav == RT_TRAV_REFERENCE)
         trav = ctx->expected_visits >= 512.0 ? RT_TRAV_WAVE : RT_TRAV_LANE;
@@ -258,8 +259,9 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     // RT_TRAV_FAST: lane re-fill pays when walks are long and their fetches miss the L2 -- scenes whose fast tree and
     // triangle positions exceed the L2s; smaller scenes take k_path with the noted primitive tests.
     const bool refill = trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && ctx->scene_bytes > kRefillSceneBytes);
+    const bool sliced = trav == RT_TRAV_FAST_SLICED;
     const bool queued = trav == RT_TRAV_FAST_QUEUED || (trav == RT_TRAV_FAST && !refill);
-    if (trav == RT_TRAV_FAST_QUEUED || trav == RT_TRAV_FAST_INLINE)
+    if (trav == RT_TRAV_FAST_QUEUED || trav == RT_TRAV_FAST_INLINE || trav == RT_TRAV_FAST_SLICED)
         trav = RT_TRAV_FAST;
     if (trav == RT_TRAV_FAST_REFILL)
         trav = RT_TRAV_FAST;
@@ -312,7 +314,18 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     // level 0, or of every 64th batch of each of this level's 64 sub-queues; no level has more batches than level 0
     // has plus one partial batch per sub-queue, so (n_batches / 64 + 66) * 64 records per sub-queue always suffice
     const size_t need_colors = (size_t)S * npix, need_q = (size_t)S * items_per_sample + (size_t)kSubQueues * 66 * 64;
-    const int levels = old ? o.bounce_limit + 1 : (o.bounce_limit > 1 ? o.bounce_limit : 1);
+    int levels = old ? o.bounce_limit + 1 : (o.bounce_limit > 1 ? o.bounce_limit : 1);
+    if (sliced) { // rounds, not bounce levels: a walk may take several; the last launch finishes whatever is left
+        static const int x_rounds = getenv("RT_X_ROUNDS") ? atoi(getenv("RT_X_ROUNDS")) : 6;
+        levels += x_rounds;
+        if (levels > kMaxLevels - 1)
+            levels = kMaxLevels - 1;
+    }
+    static const int x_slice = getenv("RT_X_SLICE") ? atoi(getenv("RT_X_SLICE")) : 64;
+    static const int x_tail_rays = getenv("RT_X_TAIL_RAYS") ? atoi(getenv("RT_X_TAIL_RAYS")) : (int)kTailRays;
+    P.slice = (uint32_t)x_slice;
+    P.tail_rays = (uint32_t)x_tail_rays;
+    const size_t rec4 = sliced ? 6 : 4; // float4 per queue record
     P.npix = (uint32_t)npix;
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
@@ -323,7 +336,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
             break;
         rt_ctx::Pipe &pp = ctx->pipes[ctx->next_pipe];
         ctx->next_pipe ^= 1;
-        if (need_colors > pp.colors_cap || need_q > pp.q_cap) {
+        if (need_colors > pp.colors_cap || need_q * rec4 > pp.q_cap) {
             RT_HIP_CHECK(ctx, hipStreamSynchronize(pp.stream));
             if (pp.d_colors) (void)hipFree(pp.d_colors);
             if (pp.d_q[0]) (void)hipFree(pp.d_q[0]);
@@ -331,10 +344,10 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
             pp.d_colors = pp.d_q[0] = pp.d_q[1] = nullptr;
             pp.colors_cap = pp.q_cap = 0;
             RT_HIP_CHECK(ctx, hipMalloc((void **)&pp.d_colors, need_colors * sizeof(float4)));
-            RT_HIP_CHECK(ctx, hipMalloc((void **)&pp.d_q[0], (need_q ? need_q : 1) * 4 * sizeof(float4)));
-            RT_HIP_CHECK(ctx, hipMalloc((void **)&pp.d_q[1], (need_q ? need_q : 1) * 4 * sizeof(float4)));
+            RT_HIP_CHECK(ctx, hipMalloc((void **)&pp.d_q[0], (need_q ? need_q : 1) * rec4 * sizeof(float4)));
+            RT_HIP_CHECK(ctx, hipMalloc((void **)&pp.d_q[1], (need_q ? need_q : 1) * rec4 * sizeof(float4)));
             pp.colors_cap = need_colors;
-            pp.q_cap = need_q;
+            pp.q_cap = need_q * rec4;
         }
         RT_HIP_CHECK(ctx, hipStreamWaitEvent(pp.stream, ctx->ev_start, 0));
         RT_HIP_CHECK(ctx, hipMemsetAsync(pp.d_levels, 0, (size_t)(levels + 1) * kSubQueues * 32 * sizeof(unsigned int), pp.stream));
@@ -362,7 +375,8 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
             // fetch latency; the spills land in the shading code, which runs once per ray); the others: uncapped
 #define RT_LAUNCH_PATH(OLD_, STATS_)                                                                                  \
     do {                                                                                                              \
-        if (walk == WALK_FAST && queued) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_QUEUED>), grid, block, 0, pp.stream, P); \
+        if (walk == WALK_FAST && sliced) hipLaunchKernelGGL((k_sliced<OLD_, STATS_>), grid, block, 0, pp.stream, P); \
+        else if (walk == WALK_FAST && queued) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_QUEUED>), grid, block, 0, pp.stream, P); \
         else if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, 0, pp.stream, P); \
         else if (walk == WALK_FAST && refill) hipLaunchKernelGGL((k_refill<OLD_, STATS_>), grid, block, 0, pp.stream, P); \
         else if (walk == WALK_FAST) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_FAST>), grid, block, 0, pp.stream, P); \
@@ -597,7 +611,7 @@ int rt_set_options(rt_ctx *ctx, const rt_options *opt) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (opt->bounce_limit < 0 || opt->bounce_limit > kMaxLevels - 2 || opt->tile_world < 1 || opt->tile_rank < 0 || opt->tile_rank >= opt->tile_world ||
         (opt->estimator != RT_EST_SD_LOOP && opt->estimator != RT_EST_OLD_RECURSIVE) || opt->traversal < 0 ||
-        opt->traversal > RT_TRAV_FAST_INLINE)
+        opt->traversal > RT_TRAV_FAST_SLICED)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad options");
     ctx->opt = *opt;
     return RT_OK;

@@ -560,6 +560,191 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
         atomicAdd(counter_slot(P, wave_id, 5), rp);
 }
 
+// Path kernel of the fast walk in SLICES (one launch per round).
+//
+// Walk lengths are heavy-tailed (bounce rays of the 18 520-triangle dragon: median 51 records, mean 75, 1 % above 267,
+// longest 445), so a wave that walks 64 rays to the end has, at the bounce levels, a fraction of its lanes busy.  Here a
+// launch takes every ray of its queue at most `slice` records further.  A ray whose walk is not over goes to the next
+// round's queue WITH its walk (next record, best candidate so far); a ray whose walk is over is shaded, and a path that
+// continues puts its new ray into the same queue.  The next round runs again in full waves: a lane idles for at most a
+// slice, not for the difference between the longest and the mean walk.  Primitive tests are noted and run together at the
+// end of the slice (WaveJobs), so that the dense walk is not interrupted for the few lanes that stand on a leaf.  A round
+// whose queue cannot fill the chip finishes everything in place (tail mode, as k_path).  Records are six float4: the
+// four of k_path plus the walk.  Same per-ray arithmetic as k_path, same results.
+template <bool OLD, bool STATS>
+__global__ void __launch_bounds__(256) k_sliced(const KParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    __shared__ WaveJobs s_jobs[4];
+    WaveJobs &J = s_jobs[threadIdx.x >> 6];
+    Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    uint32_t sub_count = 0u, sub_end = 0u;
+    uint32_t n_batches;
+    if (P.level == 0) {
+        n_batches = (P.n_items + 63u) >> 6;
+    } else {
+        sub_count = P.sub_in[lane * 32u];
+        sub_end = (sub_count + 63u) >> 6;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)sub_end, off, 64);
+            if ((int)lane >= off)
+                sub_end += up;
+        }
+        n_batches = (uint32_t)__builtin_amdgcn_readlane((int)sub_end, 63);
+    }
+    if (n_batches == 0u)
+        return;
+    const uint32_t n_in = P.level == 0 ? P.n_items : n_batches * 64u;
+    const bool tail = P.tail != 0 || (P.level >= 1 && n_in <= P.tail_rays);
+    const int slice = tail ? 0x7FFFFFFF : (int)P.slice;
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr uint32_t kChunk = 4u;
+    const uint32_t my_q = wave_id & (uint32_t)(kSubQueues - 1);
+    const uint32_t my_count = P.level == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sub_count, (int)my_q);
+    const uint32_t my_batches = P.level == 0 ? (n_batches > my_q ? (n_batches - my_q + (uint32_t)kSubQueues - 1u) / (uint32_t)kSubQueues : 0u)
+                                             : (my_count + 63u) >> 6;
+    const uint32_t chunk = P.level == 0 ? kChunk : 1u;
+    const uint32_t n = P.n_fnodes * 32u;
+    J.key[lane] = ~0ull;
+    if (lane == 0)
+        J.count = 0u;
+    uint32_t next = 0u, left = 0u;
+    for (;;) {
+        if (left == 0u) {
+            unsigned int b = 0;
+            if (lane == 0)
+                b = atomicAdd(P.sub_cursor + my_q * 32u, chunk);
+            next = __builtin_amdgcn_readfirstlane(b);
+            left = chunk;
+        }
+        const uint32_t b = next;
+        if (b >= my_batches)
+            break;
+        next++;
+        left--;
+        uint32_t out_q;
+        bool live;
+        Path path;
+        uint32_t cidx = 0;
+        Walk w = {0u, kNone, kNone, 0.0f, slice};
+        Best best = {__builtin_inff(), 0.0f, 0.0f, kNone};
+        uint32_t bpos = kNone;
+        float bm = 0.0f;
+        if (P.level == 0) {
+            const uint32_t batch = my_q + b * (uint32_t)kSubQueues;
+            live = camera_path<OLD>(P, batch * 64u + lane, path, cidx);
+            out_q = my_q;
+        } else {
+            const uint32_t local = b * 64u + lane;
+            live = local < my_count;
+            out_q = (my_q + b) & (uint32_t)(kSubQueues - 1);
+            path.o = path.d = mk3(1.f, 1.f, 1.f);
+            path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
+            path.rr = 1.0f;
+            path.depth = 0;
+            path.key = 0;
+            if (live) {
+                const size_t g = (size_t)my_q * P.sub_cap + local;
+                const float4 r0 = P.q_in[6 * g], r1 = P.q_in[6 * g + 1], r2 = P.q_in[6 * g + 2], r3 = P.q_in[6 * g + 3],
+                             r4 = P.q_in[6 * g + 4], r5 = P.q_in[6 * g + 5];
+                path.o = mk3(r0.x, r0.y, r0.z);
+                path.d = mk3(r0.w, r1.x, r1.y);
+                path.thr = make_float4(r1.z, r1.w, r2.x, r2.y);
+                path.rr = r2.z;
+                path.key = __float_as_uint(r2.w);
+                cidx = __float_as_uint(r3.x);
+                path.depth = (int)__float_as_uint(r3.y);
+                w.idx = __float_as_uint(r3.z);
+                best.ref = __float_as_uint(r3.w);
+                best.t = r4.x;
+                best.u = r4.y;
+                best.v = r4.z;
+                bpos = __float_as_uint(r4.w);
+                bm = r5.x;
+                w.inner_end = __float_as_uint(r5.y);
+                w.mesh_m = r5.z;
+                w.mesh = __float_as_uint(r5.w);
+            }
+        }
+        for (;;) {
+            if (__ballot(live) == 0ull)
+                break;
+            bool ended = false;
+            if (live) {
+                path.inv = mk3(1.0f / path.d.x, 1.0f / path.d.y, 1.0f / path.d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
+                if (w.idx == 0u)
+                    cnt.rays++; // a walk starts at record 0 and never returns to it
+                fast_walk_from<OLD, STATS, -1>(P, path.o, path.d, path.inv, w, cnt, [&](const Cand &c) {
+                    if ((c.t < best.t || (c.t == best.t && c.pos < bpos)) && c.t < __builtin_inff()) {
+                        best = Best{c.t, c.u, c.v, c.ref};
+                        bpos = c.pos;
+                        bm = fmaxf(c.m, c.mesh_m);
+                    }
+                }, [&](const uint32_t sphere, const uint32_t slot, const float m) -> bool {
+                    const uint32_t j = atomicAdd(&J.count, 1u);
+                    if (!(j < kJobCap && slot < kJobSphere))
+                        return false; // no room: the walk runs the test itself
+                    J.jobs[j] = make_uint2((lane << kJobSlotBits) | (sphere != 0u ? kJobSphere : 0u) | slot, __float_as_uint(m));
+                    return true;
+                });
+            }
+            // the noted tests of this slice, then every lane's best is complete up to where its walk stands
+            resolve_jobs<OLD>(P, lane, path.o, path.d, J);
+            take_noted_result(live, lane, J, best, bpos, bm);
+            J.key[lane] = ~0ull;
+            if (live && !(w.idx < n)) {
+                if (best.ref != kNone && (bm > best.t || P.force_replay != 0)) { // see closest_hit_fast
+                    cnt.replay++;
+                    replay_ordered<OLD, STATS>(P, path.o, path.d, path.inv, best, cnt);
+                }
+                ended = shade_path<OLD, STATS>(P, path, best, cidx, cnt);
+                w = Walk{0u, kNone, kNone, 0.0f, slice};
+                best = Best{__builtin_inff(), 0.0f, 0.0f, kNone};
+                bpos = kNone;
+                bm = 0.0f;
+            }
+            live = live && !ended;
+            if (!tail)
+                break;
+        }
+        if (tail)
+            continue;
+        // ---- unfinished walks and continuing paths go to the next round's queue, compacted per wave ----
+        const unsigned long long cmask = __ballot(live);
+        if (cmask != 0ull) {
+            unsigned int obase = 0;
+            if (lane == 0)
+                obase = atomicAdd(P.sub_out + out_q * 32u, (unsigned int)__builtin_popcountll(cmask));
+            obase = __builtin_amdgcn_readfirstlane(obase);
+            if (live) {
+                const size_t slot = (size_t)out_q * P.sub_cap + (size_t)obase + (size_t)__builtin_popcountll(cmask & below);
+                P.q_out[6 * slot] = make_float4(path.o.x, path.o.y, path.o.z, path.d.x);
+                P.q_out[6 * slot + 1] = make_float4(path.d.y, path.d.z, path.thr.x, path.thr.y);
+                P.q_out[6 * slot + 2] = make_float4(path.thr.z, path.thr.w, path.rr, __uint_as_float(path.key));
+                P.q_out[6 * slot + 3] = make_float4(__uint_as_float(cidx), __uint_as_float((uint32_t)path.depth), __uint_as_float(w.idx),
+                                                    __uint_as_float(best.ref));
+                P.q_out[6 * slot + 4] = make_float4(best.t, best.u, best.v, __uint_as_float(bpos));
+                P.q_out[6 * slot + 5] = make_float4(bm, __uint_as_float(w.inner_end), w.mesh_m, __uint_as_float(w.mesh));
+            }
+        }
+    }
+    unsigned long long r = wave_sum(cnt.rays);
+    if (lane == 0 && r != 0ull)
+        atomicAdd(counter_slot(P, wave_id, 0), r);
+    if (STATS) {
+        unsigned long long bx = wave_sum(cnt.box), t = wave_sum(cnt.tri), sp = wave_sum(cnt.sph), h = wave_sum(cnt.trih);
+        if (lane == 0 && (r | bx | t | sp | h) != 0ull) {
+            atomicAdd(counter_slot(P, wave_id, 1), bx);
+            atomicAdd(counter_slot(P, wave_id, 2), t);
+            atomicAdd(counter_slot(P, wave_id, 3), sp);
+            atomicAdd(counter_slot(P, wave_id, 4), h);
+        }
+    }
+    unsigned long long rp = wave_sum(cnt.replay);
+    if (lane == 0 && rp != 0ull)
+        atomicAdd(counter_slot(P, wave_id, 5), rp);
+}
+
 // Folds the S per-sample colours of every owned pixel into the running mean, in sample order:
 // pixel = (pixel*(n-1) + colour_n)/n, Renderer/TraceMethods.cpp:59.
 __global__ void __launch_bounds__(256) k_fold(float4 *image, const float4 *colors, uint32_t npix, int W, int tiles_x,

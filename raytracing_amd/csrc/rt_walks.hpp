@@ -659,9 +659,10 @@ struct Walk {
     uint32_t mesh;      // OLD: reference position of the enclosing mesh leaf, kNone outside a mesh
     uint32_t inner_end; // OLD: byte offset where that mesh's inline hierarchy ends
     float mesh_m;       // OLD: entry distance of that mesh leaf's box
+    int slice;          // BURST < 0: records this call may take the walk further
 };
 
-// BURST = 0: the whole walk.  BURST > 0: at most that many records, resuming from and saving to `w` (the loop itself
+// BURST = 0: the whole walk.  BURST > 0: at most that many records (BURST < 0: at most w.slice), resuming from and saving to `w` (the loop itself
 // runs on local copies either way).
 // `note(is_sphere, slot, entry distance)` may take a primitive test off the walk's hands (it returns true and the caller
 // runs the test later, see WaveJobs); the default takes none.
@@ -675,9 +676,9 @@ RT_D void fast_walk_from(const KParams &P, const f3 o, const f3 d, const f3 inv,
     uint32_t idx = w.idx;
     uint32_t mesh = w.mesh, inner_end = w.inner_end;
     float mesh_m = w.mesh_m;
-    int budget = BURST;
+    int budget = BURST > 0 ? BURST : w.slice;
     while (idx < n) {
-        if (BURST > 0) {
+        if (BURST != 0) {
             if (budget-- == 0)
                 break;
         }
@@ -766,7 +767,7 @@ RT_D void fast_walk_from(const KParams &P, const f3 o, const f3 d, const f3 inv,
             inner_end = skip;
         }
     }
-    if (BURST > 0) {
+    if (BURST != 0) {
         w.idx = idx;
         w.mesh = mesh;
         w.inner_end = inner_end;

@@ -6,7 +6,7 @@ import numpy as np
 from . import _native as N
 
 EST_SD_LOOP, EST_OLD_RECURSIVE = 0, 1
-TRAV_AUTO, TRAV_LANE, TRAV_WAVE, TRAV_NESTED, TRAV_FAST, TRAV_FAST_REPLAY, TRAV_REFERENCE, TRAV_FAST_REFILL, TRAV_BRUTE, TRAV_FAST_QUEUED, TRAV_FAST_INLINE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+TRAV_AUTO, TRAV_LANE, TRAV_WAVE, TRAV_NESTED, TRAV_FAST, TRAV_FAST_REPLAY, TRAV_REFERENCE, TRAV_FAST_REFILL, TRAV_BRUTE, TRAV_FAST_QUEUED, TRAV_FAST_INLINE, TRAV_FAST_SLICED = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 MISS = 0xFFFFFFFF
 
 _STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_HIP", -4: "RT_ERR_NO_SCENE",

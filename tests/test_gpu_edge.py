@@ -10,7 +10,7 @@ from helpers import O, R, WL, bits, objparse, oracle_camera
 
 pytestmark = pytest.mark.gpu
 
-TRAVS = [R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE, R.TRAV_LANE, R.TRAV_WAVE, R.TRAV_NESTED]
+TRAVS = [R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE, R.TRAV_FAST_SLICED, R.TRAV_LANE, R.TRAV_WAVE, R.TRAV_NESTED]
 
 
 @pytest.fixture(scope="module")

@@ -28,7 +28,7 @@ def _compare(tracer, ps, os_, cam, w, h, spp, bounce, seed, jitter=0.001):
     tracer.set_camera(cam)
     opt = O.make_options(bounce_limit=bounce, seed=seed, jitter=jitter, trig=O.TRIG_POLY, accum=O.ACCUM_FORWARD)
     oimg, oprim, ost = os_.render(oracle_camera(cam), opt, w, h, 1, spp, want_primary=True)
-    for trav in (R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED, R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE):   # every traversal variant: same bits
+    for trav in (R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED, R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE, R.TRAV_FAST_SLICED):   # every traversal variant: same bits
         tracer.set_options(bounce_limit=bounce, estimator=R.EST_OLD_RECURSIVE, seed=seed, jitter=jitter,
                            collect_stats=True, traversal=trav)
         img, prim, st = tracer.trace(w, h, 1, spp, want_primary=True)
@@ -121,12 +121,12 @@ def test_full_size_fast_vs_reference_order(tracer):
     tracer.upload(ps)
     tracer.set_camera(WL.RTIOW_CAMERA)
     out = {}
-    for trav in (R.TRAV_FAST, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE, R.TRAV_LANE):
+    for trav in (R.TRAV_FAST, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE, R.TRAV_FAST_SLICED, R.TRAV_LANE):
         tracer.set_options(bounce_limit=8, estimator=R.EST_OLD_RECURSIVE, seed=42, traversal=trav)
         out[trav] = tracer.trace(1920, 1080, 1, 3, want_primary=True)
     fi, fp, fs = out[R.TRAV_FAST]
     assert fs.replays > 100
-    for trav in (R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE, R.TRAV_LANE):
+    for trav in (R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE, R.TRAV_FAST_SLICED, R.TRAV_LANE):
         oi, op, os2 = out[trav]
         assert fs.rays == os2.rays
         assert np.array_equal(fp, op)

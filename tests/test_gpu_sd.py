@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 # per-lane walk, the first-generation nested-loop kernel (these three perform the reference's own tests, so
 # their test counts equal the oracle's too), the fast walk over the device's own hierarchy, and the fast
 # walk with every ray forced through its ordered replay
-TRAVS = [R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED, R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE]
+TRAVS = [R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED, R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE, R.TRAV_FAST_SLICED]
 REFERENCE_ORDER = (R.TRAV_WAVE, R.TRAV_LANE, R.TRAV_NESTED)
 
 
@@ -189,11 +189,11 @@ def test_full_size_properties_fast_vs_reference_order(tracer):
     tracer.upload(ps)
     tracer.set_camera(WL.DRAGON_18520_CAMERA)
     out = {}
-    for trav in (R.TRAV_FAST, R.TRAV_FAST_INLINE, R.TRAV_FAST_REFILL, R.TRAV_WAVE):
+    for trav in (R.TRAV_FAST, R.TRAV_FAST_INLINE, R.TRAV_FAST_REFILL, R.TRAV_FAST_SLICED, R.TRAV_WAVE):
         tracer.set_options(bounce_limit=8, seed=1, traversal=trav)
         out[trav] = tracer.trace(1920, 1080, 1, 2, want_primary=True)
     fi, fp, fs = out[R.TRAV_FAST]
-    for trav in (R.TRAV_FAST_INLINE, R.TRAV_FAST_REFILL, R.TRAV_WAVE):
+    for trav in (R.TRAV_FAST_INLINE, R.TRAV_FAST_REFILL, R.TRAV_FAST_SLICED, R.TRAV_WAVE):
         wi, wp, ws = out[trav]
         assert fs.rays == ws.rays
         assert np.array_equal(fp, wp)
