@@ -106,8 +106,8 @@ enum {
  *   order over the reference's node boxes; they differ only in how node records are fetched.
  *   FAST derives the same result from the reference's LEAF boxes alone, walking a surface-area-heuristic
  *   hierarchy of exact unions the upload builds above them (see rt_upload_scene); it does far fewer tests
- *   when the reference's interior boxes prune badly.  The library picks how the walk is run: FAST_QUEUED for
- *   scenes that fit the L2s, FAST_REFILL beyond; FAST_INLINE is the plain form.  FAST_REPLAY forces every ray
+ *   when the reference's interior boxes prune badly.  The library picks how the walk is run: for scenes that
+ *   fit the L2s FAST_SLICED (flat scene) or FAST_QUEUED (pointer scene), FAST_REFILL beyond; FAST_INLINE is the plain form.  FAST_REPLAY forces every ray
  *   through FAST's ordered replay procedure, which normally resolves only rays whose winning hit lies in front of
  *   its own leaf box's entry distance (a verification aid). */
 enum {
