@@ -222,7 +222,7 @@ def main():
             "config": {"workload": wl.name, "width": W, "height": H, "spp_per_step_per_gpu": spp,
                        "bounce_limit": wl.bounce_limit, "rays_per_step_per_gpu": int(st.rays // args.steps),
                        "traversal": "fast walk (own hierarchy over the reference's leaf boxes; hits bit-identical "
-                                    "to the reference-order walk)",
+                                    "to the reference-order walk), primitive tests noted and run 64 at a time",
                        "parallelism": "single GPU" if world == 1 else
                                       "scene replicated, interleaved 8x8 image tiles per GPU (tile k -> GPU k % N), steps accumulate on "
                                       "the device, one RCCL reduce of the zero-padded W*H*4 float image at the end of the render"
@@ -231,7 +231,7 @@ def main():
                                       "reduce of the W*H*4 float mean at the end of the render"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_path (k_refill for scenes larger than the L2s), one launch per bounce level, + k_fold = one trace call",
+                         "kernel": "k_sliced (flat scenes within the L2s; k_path for pointer scenes, k_refill beyond the L2s), one launch per round / bounce level, + k_fold = one trace call",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(alg_bytes),
                          "note": "algorithmic bytes = the tests this walk performs x their record payload + the "
                                  "per-sample colour traffic; node and triangle records are L2-resident for this "
