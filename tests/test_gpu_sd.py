@@ -158,7 +158,7 @@ def test_dragon18520_small(tracer, trav):
     assert np.array_equal(bits(img), bits(oimg))
 
 
-@pytest.mark.parametrize("trav", [R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_LANE])
+@pytest.mark.parametrize("trav", [R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL, R.TRAV_FAST_SLICED, R.TRAV_LANE])
 def test_dragon_field_k2(tracer, trav):
     """A 2 x 2 grid of translated dragon copies flattened into one triangle list (the small case of the
     instanced dragon field), looked at along the rows so that rays cross several copies."""
@@ -180,6 +180,26 @@ def test_dragon_field_k2(tracer, trav):
         assert np.count_nonzero(prim != oprim) == 0
         check_counts(trav, st, ost)
         assert np.array_equal(bits(img), bits(oimg))
+
+
+def test_scene_beyond_the_l2s_every_fast_variant_agrees(tracer):
+    """5 x 5 copies of the 18 520-triangle dragon (463 000 triangles: fast tree + positions = 52 MB, more than the L2s hold),
+    the size from which RT_TRAV_FAST runs the re-fill kernel; the oracle is too slow for this scene at a useful image
+    size, so the fast variants, which are separate kernels, are held to each other bit for bit."""
+    tris, _ = objparse.load_obj(WL.DRAGON_18520)
+    ps = R.SdScene().add_model(WL.dragon_grid_tris(tris, 5)).finalize()
+    tracer.upload(ps)
+    tracer.set_camera(WL.field_camera(5))
+    out = {}
+    for trav in (R.TRAV_FAST, R.TRAV_FAST_REFILL, R.TRAV_FAST_SLICED, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE):
+        tracer.set_options(bounce_limit=8, seed=5, collect_stats=True, traversal=trav)
+        out[trav] = tracer.trace(960, 540, 1, 2, want_primary=True)
+    fi, fp, fs = out[R.TRAV_FAST]
+    assert (fp != R.MISS).sum() > 50000 and fs.replays > 0
+    for trav, (oi, op, os2) in out.items():
+        assert (os2.rays, os2.box_tests, os2.tri_tests, os2.tri_hits) == (fs.rays, fs.box_tests, fs.tri_tests, fs.tri_hits), trav
+        assert np.array_equal(op, fp), trav
+        assert np.array_equal(bits(oi), bits(fi)), trav
 
 
 def test_full_size_properties_fast_vs_reference_order(tracer):
