@@ -226,3 +226,23 @@ def test_more_noted_tests_than_a_wave_can_hold(tracer):
     cam = R.Camera(1.0, (0.0, 0.0, 1.0), 2.0, 16.0 / 9.0, (0.0, 0.0, -2.0))
     prim = compare(tracer, ps, os_, cam, 160, 90, spp=3, min_hits=160 * 90 // 2)
     assert len(np.unique(prim)) > 40
+
+
+def test_random_soups_every_fast_variant_against_the_oracle(tracer):
+    """Random triangle soups (dense overlap: long candidate lists, many bounces between nearby triangles), random cameras:
+    every traversal against the oracle, bit for bit."""
+    rng = np.random.default_rng(2024)
+    for case in range(4):
+        n = (60, 400, 1500, 3000)[case]
+        c = rng.uniform(-1.0, 1.0, size=(n, 3)).astype(np.float32) * np.array([1.0, 0.6, 1.0], dtype=np.float32)
+        a = rng.normal(size=(n, 3)).astype(np.float32) * (0.5 if case < 2 else 0.15)
+        b2 = rng.normal(size=(n, 3)).astype(np.float32) * (0.5 if case < 2 else 0.15)
+        nrm = np.cross(a, b2)
+        nrm /= (np.linalg.norm(nrm, axis=1, keepdims=True) + 1e-12)
+        tris = np.zeros((n, 3, 8), dtype=np.float32)
+        tris[:, 0, :3], tris[:, 1, :3], tris[:, 2, :3] = c, c + a, c + b2
+        tris[:, :, 3:6] = nrm[:, None, :]
+        ps, os_ = both_scenes([tris.reshape(n, 24)])
+        eye = tuple(float(v) for v in rng.uniform(-0.3, 0.3, size=3) + np.array([0.0, 0.0, 2.5 - case * 0.6]))
+        cam = R.Camera(1.0, eye, 2.0, 16.0 / 9.0, (0.0, 0.0, 0.0))
+        compare(tracer, ps, os_, cam, 128, 72, spp=2, seed=case + 1, min_hits=128 * 72 // 4)
