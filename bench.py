@@ -216,6 +216,7 @@ def main():
         out = {
             "metric": "Mrays/s (all bounces)", "value": rays_total / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "msamples_per_s": (W * H * spp * args.steps * (1 if tile_split else world)) / elapsed / 1e6,
             "higher_is_better": True, "scaling": "strong" if tile_split else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "Stanford Dragon mesh bundled with the reference (data/models), no external data"
                     if wl.estimator == R.EST_SD_LOOP else "synthetic",
