@@ -936,6 +936,8 @@ RT_D void resolve_jobs(const KParams &P, const uint32_t lane, const f3 o, const 
             }
         } else if (valid) {
             const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
+            // the whole record before the test starts, as in fast_walk_from (q2.w, the position, is needed by every hit)
+            asm volatile("" : : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w), "v"(q2.x), "v"(q2.w));
             const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
             const float EPSILON = 1e-7f;
             f3 h = cross3(rd, e2);
