@@ -107,9 +107,9 @@ enum {
  *   FAST derives the same result from the reference's LEAF boxes alone, walking a surface-area-heuristic
  *   hierarchy of exact unions the upload builds above them (see rt_upload_scene); it does far fewer tests
  *   when the reference's interior boxes prune badly.  The library picks how the walk is run: for scenes that
- *   fit the L2s FAST_SLICED (flat scene) or FAST_QUEUED (pointer scene), FAST_REFILL beyond; FAST_INLINE is the plain form.  FAST_REPLAY forces every ray
- *   through FAST's ordered replay procedure, which normally resolves only rays whose winning hit lies in front of
- *   its own leaf box's entry distance (a verification aid). */
+ *   fit the L2s FAST_SLICED (flat scene) or FAST_QUEUED (pointer scene), FAST_REFILL beyond; FAST_INLINE is the
+ *   plain form.  FAST_REPLAY forces every ray through FAST's ordered replay procedure, which normally resolves
+ *   only rays whose winning hit lies in front of its own leaf box's entry distance (a verification aid). */
 enum {
     RT_TRAV_AUTO = 0,      /* = RT_TRAV_FAST; = RT_TRAV_REFERENCE for an uploaded tree in which some interior box does not
                               contain its children's boxes (the reference's builders never produce one; FAST is exact
@@ -129,10 +129,11 @@ enum {
                                reference never traces this way: all triangles in storage order.  A debugging aid: time grows
                                with rays x primitives */
     RT_TRAV_FAST_QUEUED = 9, /* FAST with the primitive tests taken out of the walk: lanes note them, the wave runs them
-                               together, 64 at a time, once its walks are over; RT_TRAV_FAST itself for scenes within the L2s */
+                               together, 64 at a time, once its walks are over; RT_TRAV_FAST itself for pointer scenes within the L2s */
     RT_TRAV_FAST_INLINE = 10, /* FAST with every primitive test run where the walk meets it */
     RT_TRAV_FAST_SLICED = 11  /* FAST in slices: a launch takes every ray a bounded number of records further and hands
-                                 unfinished walks, with their state, to the next launch; primitive tests noted */
+                                 unfinished walks, with their state, to the next launch; primitive tests noted; RT_TRAV_FAST itself
+                                 for flat scenes within the L2s */
 };
 
 typedef struct rt_options {
