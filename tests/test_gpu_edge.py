@@ -246,3 +246,49 @@ def test_random_soups_every_fast_variant_against_the_oracle(tracer):
         eye = tuple(float(v) for v in rng.uniform(-0.3, 0.3, size=3) + np.array([0.0, 0.0, 2.5 - case * 0.6]))
         cam = R.Camera(1.0, eye, 2.0, 16.0 / 9.0, (0.0, 0.0, 0.0))
         compare(tracer, ps, os_, cam, 128, 72, spp=2, seed=case + 1, min_hits=128 * 72 // 4)
+
+
+def test_load_and_trace_from_different_threads(tracer):
+    """The interface demands that load() and trace() may come from any thread (Renderer/RenderInterfaces.hpp:4-10, 14-20;
+    the reference takes a unique_lock in load and a shared_lock in trace): one thread keeps replacing the scene while
+    another keeps tracing; every frame must be exactly the frame of one scene or of the other, never a mixture."""
+    import threading
+    tris_a, _ = objparse.load_obj(WL.DRAGON_2426)
+    tris_b, _ = objparse.load_obj(WL.CYLINDER)
+    scene_a, _ = both_scenes([tris_a])
+    scene_b, _ = both_scenes([tris_b * np.float32(0.05) + np.float32(0.0)])
+    cam = WL.DRAGON_2426_CAMERA
+    tracer.set_camera(cam)
+    tracer.set_options(bounce_limit=4, seed=9, traversal=R.TRAV_FAST)
+    expected = []
+    for sc in (scene_a, scene_b):
+        tracer.upload(sc)
+        img, _, _ = tracer.trace(96, 54, 1, 2)
+        expected.append(bits(img).copy())
+    assert not np.array_equal(expected[0], expected[1])
+    errors, seen = [], set()
+
+    def loader():
+        try:
+            for i in range(30):
+                tracer.upload(scene_a if i % 2 == 0 else scene_b)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def render():
+        try:
+            for _ in range(60):
+                img, _, _ = tracer.trace(96, 54, 1, 2)
+                b = bits(img)
+                which = 0 if np.array_equal(b, expected[0]) else 1 if np.array_equal(b, expected[1]) else -1
+                seen.add(which)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=loader), threading.Thread(target=render)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert -1 not in seen and seen
