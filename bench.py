@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the HIP path tracer: Mrays/s (all bounces), one JSON line on rank 0.
 
-A step is one trace pass (spp samples per pixel) over the whole frame of the workload.  With N > 1
-(launched under torch.distributed.run, one rank per GPU) every rank traces the same frame with its own
-sample-index range (weak scaling: spp per GPU fixed) and the per-rank means are summed onto rank 0 with
-one RCCL reduce per step.
+A step is one trace pass of `spp` samples per pixel over the whole frame of the workload (the batch: W x H x spp pixel
+samples).  The K timed steps accumulate progressively into one running-mean image on the device, as the reference's
+frame loop does (Renderer/TracerImpl.cpp:9-12).  With N > 1 (launched under torch.distributed.run, one rank per GPU) the
+same K steps are shared by the ranks -- interleaved 8x8 image tiles (the default) or sample-index ranges -- and the
+render ends with ONE RCCL reduce of the W*H*4 float image onto rank 0, inside the timed region: total work is fixed,
+"scaling": "strong".
 """
 import argparse
 import json
@@ -16,78 +18,116 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec
-VALU_PEAK_TOPS = 78.6         # 256 CU x 128 lanes x 2.4 GHz, one op per lane-cycle (the path forbids FMA)
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E nominal
+VALU_PEAK_TOPS = 78.6         # 256 CU x 128 lanes x 2.4 GHz, one op per lane-cycle (the path forbids FMA contraction)
+L2_BYTES = 32 << 20           # 8 XCDs x 4 MB: scenes whose node + triangle-position records fit are served from the L2s
+
+
+def host_cpu():
+    """Model string, logical CPUs of the machine, CPUs this process may use, and the thread count the harness asks
+    worker pools to keep to (OMP_NUM_THREADS on the GPU box: the box's CPU share for one GPU)."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    return model, logical, usable, share
+
+
+def oracle_scene(wl):
+    """The workload's scene rebuilt for the CPU oracle (cpu_baseline leg only)."""
+    from oracle import oracle as O
+    import raytracing_amd as R
+    if wl.estimator == R.EST_SD_LOOP:
+        osc = O.SdScene()
+        for tris in wl.models:
+            osc.add_model(tris, [len(tris)])
+        osc.finalize()
+        return osc
+    osc = O.OldScene()
+    for c, rad, kind, alb, param in wl.spheres:
+        osc.add_sphere(c, rad, kind, alb, param)
+    osc.build()
+    return osc
 
 
 def cpu_baseline(wl, args):
-    """Times the CPU oracle (a port of the reference path) on a bounded sample of the workload: the same
-    scene, camera and bounce limit at reduced resolution and a few spp (about 10-20 s of CPU work)."""
-    from oracle import objparse, oracle as O
+    """Times the CPU oracle (a port of the reference path) on a bounded sample of the workload: the same scene, camera
+    and bounce limit at reduced resolution and a few spp (about 10-20 s of CPU work), (ii) one row band per host thread
+    the process may use and (i) the reference's own schedule of 16 bands with a lock per pixel."""
+    from oracle import oracle as O
     from raytracing_amd import workloads as WL
     import raytracing_amd as R
-    threads = min(os.cpu_count() or 1, 16)
-    div = args.cpu_div
-    w, h = max(wl.width // div, 16), max(wl.height // div, 9)
+    model, logical, usable, share = host_cpu()
+    threads = min(usable, share) if share > 0 else usable
+    if args.cpu_threads:
+        threads = args.cpu_threads
     cam = wl.camera
     ocam = O.make_camera(cam.focal_length, cam.position, cam.look_at, cam.width, cam.aspect_ratio)
-    if wl.estimator == R.EST_SD_LOOP:
-        osc = O.SdScene()
-        tris, sizes = objparse.load_obj(wl.obj_path)
-        if wl.field_k:
-            tris = WL.dragon_grid_tris(tris, wl.field_k)
-            sizes = [len(tris)]
-        osc.add_model(tris, sizes)
-        osc.finalize()
-    else:
-        osc = O.OldScene()
-        for c, rad, kind, alb, param in (WL.rtiow_spheres() if wl.name.startswith("rtiow") else WL.small_sphere_scene()):
-            osc.add_sphere(c, rad, kind, alb, param)
-        osc.build()
-    # (ii) fair host schedule: one row band per core, no per-pixel lock
+    osc = oracle_scene(wl)
     # (polynomial cos/sin so that its visit counts can be compared with the GPU's; the cost of the two
     # trig evaluations per bounce is negligible next to the traversal)
     opt = O.make_options(bounce_limit=wl.bounce_limit, seed=wl.seed, jitter=wl.jitter, trig=O.TRIG_POLY,
                          threads=threads, lock_per_pixel=0, accum=O.ACCUM_FORWARD)
-    # the sample is sized from a 1-spp probe so that each of the two timed renders is about args.cpu_seconds of
-    # CPU work whatever the workload costs per ray
-    _, _, probe = osc.render(ocam, opt, w, h, 1, 1)
-    spp = args.cpu_spp or int(min(max(args.cpu_seconds / max(probe.seconds, 1e-4), 1), 256))
+    # The sample is sized from a probe (1 spp at 1/32 of the resolution) so that each of the two timed renders is about
+    # args.cpu_seconds of CPU work whatever the workload costs per ray: the largest resolution among 1/4 ... 1/32 at
+    # which one sample per pixel fits, and as many samples per pixel as fit (at most 256).
+    pw, ph = max(wl.width // 32, 16), max(wl.height // 32, 9)
+    _, _, probe = osc.render(ocam, opt, pw, ph, 1, 1)
+    per_pixel = max(probe.seconds, 1e-5) / (pw * ph)
+    div = args.cpu_div
+    while div < 32 and per_pixel * (wl.width // div) * (wl.height // div) > args.cpu_seconds:
+        div *= 2
+    w, h = max(wl.width // div, 16), max(wl.height // div, 9)
+    spp = args.cpu_spp or int(min(max(args.cpu_seconds / (per_pixel * w * h), 1), 256))
     args.cpu_spp = spp
     _, _, st = osc.render(ocam, opt, w, h, 1, spp)
-    # (i) the reference's own schedule: 16 row bands per sample and a shared_lock per pixel
+    # (i) the reference's own schedule: 16 row bands per sample and a shared_lock per pixel (TraceMethods.cpp:57, :61-78)
     opt_ref = O.make_options(bounce_limit=wl.bounce_limit, seed=wl.seed, jitter=wl.jitter, trig=O.TRIG_LIBM,
                              threads=16, lock_per_pixel=1, accum=O.ACCUM_RECURSIVE)
     _, _, st_ref = osc.render(ocam, opt_ref, w, h, 1, spp)
     return {"value": st.rays / st.seconds / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{wl.name} scene/camera/bounce limit at {w}x{h}, {args.cpu_spp} spp ({st.rays} rays, {st.seconds:.2f} s)",
+            "host_cpu_model": model, "host_logical_cpus": logical, "cpus_usable_by_this_process": usable,
+            "thread_cap_of_the_box": share or None,
             "reference_schedule_value": st_ref.rays / st_ref.seconds / 1e6,
-            "reference_schedule": "16 std::async row bands + shared_lock per pixel"}, st, (w, h)
+            "reference_schedule": "16 std::async row bands + shared_lock per pixel (TraceMethods.cpp:57, :61-78)"}, st, (w, h)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dragon18520_1080p")
-    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (0 = the workload's)")
-    ap.add_argument("--split", choices=("sample", "tile"), default="sample",
-                    help="N > 1: sample = every rank renders its own samples of the whole frame (weak scaling, the default); "
-                         "tile = the ranks share the tiles of one frame (strong scaling)")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (0 = the workload's bench_spp)")
+    ap.add_argument("--split", choices=("tile", "sample"), default="tile",
+                    help="N > 1: tile = the ranks share the 8x8 tiles of every step (the default); "
+                         "sample = the ranks share the samples of every step")
     ap.add_argument("--traversal", type=int, default=4, help="RT_TRAV_* of the timed steps (4 = fast walk, 7 = with lane re-fill)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-counts", action="store_true",
                     help="skip the untimed pass that counts the tests of the reference-order walk")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed primary-only and host-copy legs")
     ap.add_argument("--cpu-div", type=int, default=4, help="cpu_baseline sample: resolution divisor")
     ap.add_argument("--cpu-spp", type=int, default=0, help="cpu_baseline sample: samples per pixel (0 = sized from a probe)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="cpu_baseline sample: target seconds per timed render")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="cpu_baseline: threads of schedule (ii) (0 = what the process may use)")
     args = ap.parse_args()
     if os.environ.get("RT_BENCH_WATCHDOG"):  # dump every thread's stack if the run is still going after that many seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
 
-    import numpy as np
     import torch
     import raytracing_amd as R
     from raytracing_amd import workloads as WL
@@ -111,62 +151,57 @@ def main():
         print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     wl = WL.make_workload(args.workload)
-    spp = args.spp or wl.spp
+    spp = args.spp or wl.bench_spp
     W, H = wl.width, wl.height
+    split = args.split
+    if split == "sample" and spp % world:
+        raise SystemExit("--split sample needs spp divisible by the number of GPUs")
+    my_spp = spp // world if split == "sample" else spp          # samples per pixel this rank renders per step
+    my_pixels = W * H                                            # ... of how many pixels (tile split: its tiles')
     tr = R.Tracer(local_rank)
     tr.upload(wl.scene)
     tr.set_camera(wl.camera)
     tr.set_stream(torch.cuda.current_stream().cuda_stream)
     img = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    share = P.share_options(split, rank, world, samples_per_rank=my_spp * max(args.steps, args.warmup, 1))
 
-    tile_split = args.split == "tile" and world > 1
+    def options(stats, traversal=args.traversal, bounce_limit=wl.bounce_limit):
+        tr.set_options(bounce_limit=bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
+                       collect_stats=stats, traversal=traversal, **share)
 
-    def options(stats, traversal=args.traversal):
-        if tile_split:  # the same samples on every rank, disjoint 8x8 tiles (tile k belongs to rank k % world)
-            tr.set_options(bounce_limit=wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
-                           collect_stats=stats, tile_rank=rank, tile_world=world, traversal=traversal)
-        else:
-            tr.set_options(bounce_limit=wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
-                           collect_stats=stats, sample_offset=P.sample_offset(rank, spp * max(args.steps, args.warmup)),
-                           traversal=traversal)
-
-    # One render = `n` steps of `spp` samples accumulated into the running mean on the device (the reference's
-    # progressive sampleCount protocol, Renderer/TracerImpl.cpp:9-12), then -- N > 1 -- ONE RCCL reduce(SUM) of the
-    # per-rank means, / world on rank 0.  Rank r draws the sample indices r * n * spp + 1 ... (r + 1) * n * spp.
-    # The steps are issued back to back with pipelining on: the tracer overlaps the latency-bound end of one step (deep
-    # bounce levels) with the start of the next on its own streams; rt_join orders the image before the reduce.
+    # The steps of a render are issued back to back with pipelining on: the tracer overlaps the latency-bound end of one
+    # chunk of samples (deep bounce levels) with the start of the next on its own streams; rt_join orders the image
+    # before the reduce.
+    options(False)
     tr.set_pipelining(True)
+    tr.reserve(W, H, my_spp)      # set-up, untimed like the upload: the timed region never allocates
+
+    def trace_pass(i):
+        tr.trace_device(W, H, 1 + i * my_spp, my_spp, img.data_ptr())
 
     def render(n):
-        for i in range(n):
-            tr.trace_device(W, H, 1 + i * spp, spp, img.data_ptr())
-        tr.join()
-        if tile_split:  # pixels of other ranks are zero here: one reduce(SUM) assembles the frame exactly
-            P.combine_tile_split(img, dst=0)
-        else:
-            P.combine_sample_split(img, dst=0)
+        P.render(trace_pass, tr.join, img, n, split, world)
 
-    # work of one trace call: counted once, untimed, by the counting variant of the same kernel
+    # work of one step: counted once, untimed, by the counting variant of the same kernels
     options(True)
-    tr.trace_device(W, H, 1, spp, img.data_ptr())
+    trace_pass(0)
     counts = tr.sync()
-    # the same rays walked in the reference's own visiting order over the reference's own boxes: what the
-    # reference traversal (and the CPU baseline) has to do for this frame
-    ref_counts = None
-    # (skipped for scenes where that walk would take minutes: the million-triangle fields)
+    # the same rays walked in the reference's own visiting order over the reference's own boxes: what the reference
+    # traversal (and the CPU baseline) has to do per ray -- on 16 spp (that walk is slow), skipped for scenes where it
+    # would take minutes (the million-triangle fields)
+    ref_counts = fast16 = None
+    ref_spp = min(my_spp, 16)
     if rank == 0 and not args.no_reference_counts and len(wl.scene.nodes()) < 200000:
+        options(True)
+        tr.trace_device(W, H, 1, ref_spp, img.data_ptr())
+        fast16 = tr.sync()
         options(True, R.TRAV_REFERENCE)
-        tr.trace_device(W, H, 1, spp, img.data_ptr())
+        tr.trace_device(W, H, 1, ref_spp, img.data_ptr())
         ref_counts = tr.sync()
-        assert ref_counts.rays == counts.rays and ref_counts.tri_hits == counts.tri_hits
+        assert ref_counts.rays == fast16.rays and ref_counts.tri_hits == fast16.tri_hits
     options(False)
     note(f"scene uploaded, work counted ({counts.rays} rays per step)")
 
-    # set-up, untimed like the upload: both of the tracer's internal pipes get their workspace (a step allocates it on
-    # first use), so that the timed region never allocates whatever W is
-    for i in range(2):
-        tr.trace_device(W, H, 1 + i * spp, spp, img.data_ptr())
-    tr.sync()
     render(args.warmup)
     tr.sync()
     note("warm-up done")
@@ -193,7 +228,9 @@ def main():
         rays_total = float(total[1])
 
     if rank == 0:
-        kernel_ms = st.kernel_ms_sum / st.launches
+        kernel_ms = st.kernel_ms_sum / st.launches   # HIP events on the tracer's streams: first start to last end / steps
+        if split == "tile" and world > 1:
+            my_pixels = sum(1 for k in range(((W + 7) // 8) * ((H + 7) // 8)) if k % world == rank) * 64
 
         def traversal_bytes(c):
             # 32 B per slab test (box + 2 links), 36 B per triangle test (3 positions), 16 B per sphere test,
@@ -203,57 +240,115 @@ def main():
         def traversal_ops(c):
             return 27 * c.box_tests + 56 * c.tri_tests + 24 * c.sph_tests + 60 * c.rays
 
-        # per pixel sample: one 16 B colour written and read once (the fold); per pixel: the 16 B mean written
-        image_bytes = (32 * W * H * spp + 16 * W * H) // (world if tile_split else 1)
+        # per pixel: the 16 B mean read and written once per step
+        image_bytes = 32 * my_pixels
         alg_bytes = traversal_bytes(counts) + image_bytes
         alg_ops = traversal_ops(counts)
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                traffic = json.load(fh).get(f"{wl.name}:{spp}:fast")
+        secs = kernel_ms * 1e-3
+        # hardware-counter figures of this workload, measured in separate rocprofv3 --pmc passes and kept with the
+        # profiles: HBM bytes per step (traffic), VALU issue utilisation, active lanes per VALU instruction
+        pmc = {}
+        ppath = os.path.join(ROOT, "profiles", "pmc_per_step.json")
+        if os.path.exists(ppath):
+            with open(ppath) as fh:
+                pmc = json.load(fh).get(f"{wl.name}:{my_spp}", {})
+        traffic = pmc.get("hbm_bytes_per_step")
+        in_l2 = wl.scene_bytes() <= L2_BYTES
+        if in_l2:
+            # node and triangle records are served by the L2s: what bounds the walk is VALU issue under divergence
+            roof = {"bound": "valu", "achieved": alg_ops / secs / 1e12, "peak": VALU_PEAK_TOPS, "unit": "Tops/s",
+                    "frac": alg_ops / secs / 1e12 / VALU_PEAK_TOPS, "traffic": traffic,
+                    "algorithmic_ops_per_launch": int(alg_ops),
+                    "note": "fp32 lane-operations the walk's own tests and the shading need (27 per slab test, 56 per "
+                            "triangle test, 24 per sphere test, 60 per ray) against the non-FMA VALU peak; the scene's "
+                            "records fit the L2s, so HBM carries only the queues and the image (hbm_*)"}
+        else:
+            roof = {"bound": "hbm", "achieved": alg_bytes / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": alg_bytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(alg_bytes),
+                    "note": "bytes the walk's own tests need (32 per slab test, 36 per triangle test, 36 of normals per "
+                            "triangle hit) + the image; the scene's records exceed the L2s"}
+        roof.update({"kernel": "one step = one trace call: k_sliced (flat scenes within the L2s), k_path (pointer scenes) or "
+                               "k_refill (beyond the L2s), one launch per round / bounce level and chunk of samples, + k_fold",
+                     "kernel_ms": kernel_ms,
+                     "hbm_achieved_GBps": traffic / secs / 1e9 if traffic else None,
+                     "hbm_frac": traffic / secs / 1e9 / HBM_PEAK_GBS if traffic else None,
+                     "valu_issue_utilisation": pmc.get("valu_issue_utilisation"),
+                     "active_lanes_per_valu_instruction": pmc.get("active_lanes"),
+                     "counters_from": pmc.get("source")})
+        primary = my_pixels * my_spp if wl.bounce_limit > 0 or wl.estimator != R.EST_SD_LOOP else 0
         out = {
             "metric": "Mrays/s (all bounces)", "value": rays_total / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "msamples_per_s": (W * H * spp * args.steps * (1 if tile_split else world)) / elapsed / 1e6,
-            "higher_is_better": True, "scaling": "strong" if tile_split else "weak", "vs_baseline": None, "dtype": "f32",
+            "msamples_per_s": (W * H * spp * args.steps) / elapsed / 1e6,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "Stanford Dragon mesh bundled with the reference (data/models), no external data"
                     if wl.estimator == R.EST_SD_LOOP else "synthetic",
-            "config": {"workload": wl.name, "width": W, "height": H, "spp_per_step_per_gpu": spp,
-                       "bounce_limit": wl.bounce_limit, "rays_per_step_per_gpu": int(st.rays // args.steps),
+            "config": {"workload": wl.name, "description": wl.description, "width": W, "height": H, "spp_per_step": spp,
+                       "bounce_limit": wl.bounce_limit, "triangles": int(len(wl.scene.tris())),
+                       "rays_per_step_per_gpu": int(st.rays // args.steps),
                        "traversal": "fast walk (own hierarchy over the reference's leaf boxes; hits bit-identical "
                                     "to the reference-order walk), primitive tests noted and run 64 at a time",
                        "parallelism": "single GPU" if world == 1 else
                                       "scene replicated, interleaved 8x8 image tiles per GPU (tile k -> GPU k % N), steps accumulate on "
                                       "the device, one RCCL reduce of the zero-padded W*H*4 float image at the end of the render"
-                                      if tile_split else
+                                      if split == "tile" else
                                       "scene replicated, sample-index range per GPU, steps accumulate on the device, one RCCL "
                                       "reduce of the W*H*4 float mean at the end of the render"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_sliced (flat scenes within the L2s; k_path for pointer scenes, k_refill beyond the L2s), one launch per round / bounce level, + k_fold = one trace call",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "note": "algorithmic bytes = the tests this walk performs x their record payload + the "
-                                 "per-sample colour traffic; node and triangle records are L2-resident for this "
-                                 "scene, so most of these bytes never reach HBM (see traffic)"},
-            "valu": {"achieved": alg_ops / (kernel_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS, "unit": "Tops/s",
-                     "frac": alg_ops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
-                     "algorithmic_ops_per_launch": int(alg_ops)},
+            "roofline": roof,
+            "rays_per_step": {"primary": int(primary), "bounce": int(counts.rays - primary),
+                              "searches_ending_on_a_triangle": int(counts.tri_hits),
+                              "note": "primary = camera rays; a camera ray that misses the scene ends its path at once"},
             "counts_per_launch": {"rays": int(counts.rays), "box_tests": int(counts.box_tests),
                                   "tri_tests": int(counts.tri_tests), "sph_tests": int(counts.sph_tests),
                                   "tri_hits": int(counts.tri_hits), "replays": int(counts.replays)},
         }
         if ref_counts is not None:
-            rb = traversal_bytes(ref_counts) + 16 * W * H
             out["reference_order_equivalent"] = {
-                "box_tests": int(ref_counts.box_tests), "tri_tests": int(ref_counts.tri_tests),
-                "sph_tests": int(ref_counts.sph_tests), "algorithmic_bytes_per_launch": int(rb),
-                "equivalent_GBps": rb / (kernel_ms * 1e-3) / 1e9,
-                "note": "tests and bytes the reference's own traversal needs for the same rays and the same hits"}
+                "spp": ref_spp, "rays": int(ref_counts.rays),
+                "box_tests_per_ray": ref_counts.box_tests / max(ref_counts.rays, 1),
+                "tri_tests_per_ray": ref_counts.tri_tests / max(ref_counts.rays, 1),
+                "fast_walk_box_tests_per_ray": fast16.box_tests / max(fast16.rays, 1),
+                "note": "tests the reference's own traversal performs for the same rays and the same hits"}
+        if world == 1 and not args.no_extras:
+            note("extra legs: camera rays alone, host-image boundary")
+            # (1) camera rays alone: the same steps with bounce limit 1 (every path ends after its first search)
+            options(False, bounce_limit=1)
+            ksteps = max(min(args.steps, 8), 2)
+            render(1)
+            tr.sync()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            render(ksteps)
+            torch.cuda.synchronize()
+            t_primary = (time.perf_counter() - t1) / ksteps
+            pst = tr.sync()
+            t_step = elapsed / args.steps
+            out["rays_per_step"].update({
+                "primary_only_ms_per_step": t_primary * 1e3,
+                "primary_Mrays_per_s": pst.rays / ksteps / t_primary / 1e6,
+                "bounce_Mrays_per_s": (counts.rays - primary) / max(t_step - t_primary, 1e-9) / 1e6 if counts.rays > primary else None,
+                "how": "primary: the same steps with bounce limit 1; bounce: the remaining rays over the remaining time"})
+            # (2) through the synchronous host-image boundary: rt_trace into page-locked memory, D2H of the mean included
+            options(False)
+            tr.set_pipelining(False)
+            hbuf = tr.alloc_host(W * H * 16)
+            tr.trace_host(W, H, 1, my_spp, hbuf)
+            t2 = time.perf_counter()
+            hrays = 0
+            for i in range(ksteps):
+                hrays += tr.trace_host(W, H, 1 + i * my_spp, my_spp, hbuf).rays
+            t_host = (time.perf_counter() - t2) / ksteps
+            tr.free_host(hbuf)
+            out["incl_d2h"] = {"value": hrays / ksteps / t_host / 1e6, "unit": "Mrays/s", "ms_per_step": t_host * 1e3,
+                               "note": "rt_trace, one synchronous call per step, the W*H*16-byte mean copied to page-locked "
+                                       "host memory inside the timed call (the reference's setData upload, Texture.cpp:86-91)"}
         if world == 1 and not args.no_cpu_baseline:
+            note("CPU baseline (two renders of about %.0f s each)" % args.cpu_seconds)
             cb, ost, (cw, ch) = cpu_baseline(wl, args)
+            note("CPU baseline done; checking its test counts against the GPU's reference-order walk")
             # same bounded sample on the GPU: counts must equal the oracle's (checker, not the thing measured)
+            tr.set_pipelining(False)
             tr.set_options(bounce_limit=wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
                            collect_stats=True, traversal=R.TRAV_REFERENCE)
             _, _, gst = tr.trace(cw, ch, 1, args.cpu_spp, want_image=False)

@@ -136,6 +136,14 @@ enum {
                                  for flat scenes within the L2s */
 };
 
+/* How the devices of one context (rt_create_multi) share a trace call.  Both are the reference's own kind of split --
+ * its 16 row bands share nothing either (Renderer/TraceMethods.cpp:61-72).
+ *   TILE:   device r of n renders the 8x8 tiles k with k % n == r for all samples; the frame is put together by
+ *           copying each device's tiles -- bit-identical to one device.
+ *   SAMPLE: device r renders its share of the call's sample indices for every pixel into a running mean of its own;
+ *           the frame is sum_r mean_r * (samples_r / samples) -- equal to one device's running mean to rounding. */
+enum { RT_SPLIT_TILE = 0, RT_SPLIT_SAMPLE = 1 };
+
 typedef struct rt_options {
     int32_t bounce_limit; /* Trace::bounceLimit, CPURayTrace/Trace.hpp:16 */
     int32_t estimator;    /* RT_EST_* */
@@ -147,6 +155,7 @@ typedef struct rt_options {
     uint32_t sample_offset; /* added to the sample index in the RNG key only: lets several contexts each
                                accumulate a mean over n samples of disjoint random streams (sample-range split) */
     int32_t traversal;      /* RT_TRAV_* */
+    int32_t multi_split;    /* RT_SPLIT_*: how a context made by rt_create_multi shares a call among its devices */
 } rt_options;
 
 typedef struct rt_stats {
@@ -167,7 +176,19 @@ typedef struct rt_stats {
 /* Creates a context on HIP device `device`.  Stands in for the constructors of the reference's
  * trace/load method objects (Renderer/TraceMethods.cpp:44, Renderer/LoadMethods.cpp:54). */
 int rt_create(rt_ctx **out, int device);
+/* One context over several HIP devices (device_ids[0 .. n_devices-1], each at most once in a real installation): the
+ * counterpart of the reference's numThreads = 16 row bands (Renderer/TraceMethods.hpp:44, TraceMethods.cpp:61-78) with
+ * GPUs for threads.  The scene is replicated on every device; each rt_trace / rt_trace_device is shared as
+ * rt_options.multi_split says, one host thread per device issuing and awaiting that device's work, and the frame is put
+ * together on device_ids[0] (peer copies over xGMI), where d_rgba of rt_trace_device must live.  rt_options.tile_rank /
+ * tile_world / sample_offset keep their meaning for the context as a whole, so processes and devices can be combined.
+ * rt_trace_device returns when the devices have finished their shares (the assembly is enqueued on the context's
+ * stream); rt_set_pipelining(1) is refused.  n_devices == 1 is rt_create. */
+int rt_create_multi(rt_ctx **out, const int *device_ids, int n_devices);
+int rt_device_count(rt_ctx *ctx); /* devices behind the context */
 void rt_destroy(rt_ctx *ctx);
+/* Text of the context's last error.  The pointer belongs to the calling thread and stays valid until that thread's next
+ * rt_last_error call, whatever other threads do with the context. */
 const char *rt_last_error(rt_ctx *ctx);
 
 /* Takes the scene snapshot the reference's load methods take (LoadSdSceneCPU::load,
@@ -183,6 +204,14 @@ int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_
 /* The camera the reference reads live each frame (DIContext.cam, Renderer/TraceMethods.cpp:51-53). */
 int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
 int rt_set_options(rt_ctx *ctx, const rt_options *opt);
+/* Allocates now everything later trace calls of up to n_samples samples per pixel on width x height frames need (the
+ * wavefront workspace of the context's internal pipes and the context's own image), so that those calls neither
+ * allocate nor wait for an allocation; without it the first call of a size does both.  The reference's counterpart is
+ * CPUImageData::resize (Renderer/TraceMethods.hpp:31-36), which sizes the trace method's buffers ahead of the loop.
+ * Footprint per device: 2 pipes x (S*W*H*16 B of colours + 2 queues of (S*items + 270 336) records of 96 B), where
+ * items = this context's pixels in whole 8x8 tiles and S = min(n_samples, 64, 192 Mi / items) samples per chunk --
+ * 4.7 GB at 1920x1080x16, 28 GB at 3840x2160 with 23 samples per chunk.  Buffers only grow; rt_destroy releases them. */
+int rt_reserve(rt_ctx *ctx, int width, int height, int n_samples);
 
 /* Zeroes the accumulated image (TracerAsync::resetSamples, Renderer/TracerImpl.cpp:18-22, together
  * with CPUImageData::resize's zero fill, Renderer/TraceMethods.hpp:31-36). */

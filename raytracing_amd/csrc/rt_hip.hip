@@ -37,6 +37,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -56,11 +57,23 @@ namespace {
 } // namespace
 
 // ===================================================================== host side of the C ABI
+
+constexpr size_t kLevelWords = (size_t)(kMaxLevels + 1) * kSubQueues * 32;
+constexpr size_t kQueueSlack = (size_t)kSubQueues * 66 * 64; // see queue_records
+
+// What one chunk of the wavefront tracer works in.
+struct Workspace {
+    float4 *colors = nullptr, *q[2] = {nullptr, nullptr};
+    unsigned int *levels = nullptr;   // per level: 64 sub-queue slots of 32 words (count, batch cursor)
+    size_t colors_cap = 0, q_cap = 0; // capacities in float4
+};
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::mutex mu;
+    std::mutex err_mu; // guards `err` alone: rt_last_error may be called while another thread is inside a long call
     std::string err;
     // scene in HBM
     float4 *d_fnodes = nullptr;
@@ -81,35 +94,43 @@ struct rt_ctx {
     // work queue head and counters
     unsigned int *d_queue = nullptr;
     unsigned long long *d_counters = nullptr;
+    bool counted = false; // something has been added to the counters since they were last read
     // one HIP event pair per launch since the last sync (the kernel time is read back in rt_sync)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t pending = 0;
     int num_cus = 0;
     int blocks_per_cu[16] = {0}; // [nested | wavefront per-lane | wavefront wave-sync | wavefront fast][estimator][stats]
-    // wavefront workspace: per-sample colour buffer, two ping-pong path queues, per-level cursors/counters
-    // Two pipes take the chunks of the wavefront tracer in turn, each with its own stream and workspace, so that the
-    // latency-bound end of one chunk (deep bounce levels: few rays, long walks) overlaps the throughput-bound start of
-    // the next.  The folds into the running mean are chained by events and stay in sample order.
+    // Two pipes take the chunks of the wavefront tracer in turn, each with its own stream and workspace (per-sample
+    // colour buffer, two ping-pong path queues, per-level cursors/counters), so that the latency-bound end of one chunk
+    // (deep bounce levels: few rays, long walks) overlaps the throughput-bound start of the next.  The folds into the
+    // running mean are chained by events and stay in sample order.
     struct Pipe {
         hipStream_t stream = nullptr;
-        float4 *d_colors = nullptr, *d_q[2] = {nullptr, nullptr};
-        unsigned int *d_levels = nullptr; // per level: 64 sub-queue slots of 32 words (count, batch cursor)
-        size_t colors_cap = 0, q_cap = 0; // capacities in float4 / records
-        hipEvent_t done = nullptr;        // recorded after the pipe's last fold
-        bool used = false;                // `done` has been recorded at least once
+        Workspace ws;
+        hipEvent_t done = nullptr; // recorded after the pipe's last fold
+        bool used = false;         // `done` has been recorded at least once
     } pipes[2];
     int next_pipe = 0;
     hipEvent_t ev_start = nullptr;  // orders a call's chunks after what precedes the call on the context's stream
     hipEvent_t last_fold = nullptr; // `done` of the pipe that ran the latest fold
     bool pipelining = false;        // rt_set_pipelining: calls may overlap; rt_join / rt_sync order their results
     bool joined = true;             // the context's stream has been made to wait for both pipes
+    // rt_create_multi: this context only coordinates; kids[r] is an ordinary context on device r of the list, and
+    // `device` / `stream` / `d_image` belong to the first device of the list, where the frame is put together.
+    std::vector<rt_ctx *> kids;
+    std::vector<float4 *> peer_img;    // root-device landing buffers for the frames of kids 1..n-1
+    std::vector<uint32_t *> peer_prim; // ... and for their primary-id images
+    std::vector<int> kid_samples;      // sample split: samples folded into each kid's own mean since the last restart
+    size_t peer_cap = 0;               // pixels the landing buffers hold
 };
 
 namespace {
 
 int fail(rt_ctx *ctx, int code, const std::string &msg) {
-    if (ctx)
+    if (ctx) {
+        std::lock_guard<std::mutex> g(ctx->err_mu);
         ctx->err = msg;
+    }
     return code;
 }
 #define RT_HIP_CHECK(ctx, expr)                                                                               \
@@ -119,6 +140,27 @@ int fail(rt_ctx *ctx, int code, const std::string &msg) {
             return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,                   \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                                   \
     } while (0)
+
+// Makes the context's device current for the duration of a call and puts the caller's device back afterwards: a host
+// application (or torch) that works on another GPU must not find its current device changed by a tracer call.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t rc;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        rc = prev == dev ? hipSuccess : hipSetDevice(dev);
+        if (prev == dev)
+            prev = -1; // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+#define RT_ON_DEVICE(ctx)                                                                                      \
+    DeviceGuard device_guard_((ctx)->device);                                                                  \
+    RT_HIP_CHECK(ctx, device_guard_.rc)
 
 void free_scene(rt_ctx *c) {
     if (c->d_nodes) (void)hipFree(c->d_nodes);
@@ -132,6 +174,14 @@ void free_scene(rt_ctx *c) {
     c->d_nodes = c->d_tri_pos = c->d_tri_nrm = c->d_spheres = c->d_mats = nullptr;
     c->n_nodes = 0;
     c->has_scene = false;
+}
+
+void free_workspace(Workspace &ws) {
+    if (ws.colors) (void)hipFree(ws.colors);
+    if (ws.q[0]) (void)hipFree(ws.q[0]);
+    if (ws.q[1]) (void)hipFree(ws.q[1]);
+    ws.colors = ws.q[0] = ws.q[1] = nullptr;
+    ws.colors_cap = ws.q_cap = 0;
 }
 
 inline float u2f(uint32_t u) {
@@ -159,10 +209,7 @@ template <int KERNEL, bool OLD, bool STATS> int occupancy(int *out) {
         *out = 8;
         return 0;
     }
-    hipError_t e = KERNEL == 3   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, WALK_FAST>, 256, 0)
-                   : KERNEL == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, WALK_WAVE>, 256, 0)
-                   : KERNEL == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_path<OLD, STATS, WALK_LANE>, 256, 0)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<OLD, STATS>, 256, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<OLD, STATS>, 256, 0);
     if (e != hipSuccess || n < 1)
         n = 1;
     if (n > 8)
@@ -190,7 +237,24 @@ int sync_all(rt_ctx *ctx) {
     return RT_OK;
 }
 
-int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim) {
+// Everything about a trace call that does not depend on the chunk: kernel parameters, which kernel, how many launches.
+struct Plan {
+    KParams P;
+    int variant = 0, walk = 0, levels = 1;
+    bool nested = false, sliced = false, queued = false, refill = false;
+    uint32_t full_grid = 1;
+    size_t rec4 = 4;            // float4 per queue record
+    size_t npix = 0, items_per_sample = 0;
+    int W = 0, H = 0, first = 1, count = 0;
+};
+
+// Queue records a chunk of `items` pixel samples needs: a sub-queue of the next level receives the continuing paths
+// (at most 64) of every 64th batch of level 0, or of every 64th batch of each of this level's 64 sub-queues; no level
+// has more batches than level 0 has plus one partial batch per sub-queue, so (n_batches / 64 + 66) * 64 records per
+// sub-queue always suffice.
+size_t queue_records(size_t items) { return items + kQueueSlack; }
+
+int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim, Plan &pl) {
     if (!ctx->has_scene)
         return fail(ctx, RT_ERR_NO_SCENE, "Scene is not loaded.");
     if (!ctx->has_camera)
@@ -200,7 +264,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     if (d_img == nullptr)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null image");
     const rt_options &o = ctx->opt;
-    KParams P;
+    KParams &P = pl.P;
     P.nodes = ctx->d_nodes;
     P.fnodes = ctx->d_fnodes;
     P.n_fnodes = ctx->n_fnodes;
@@ -244,7 +308,6 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     P.cam_h = c.height;
     P.focal = c.focal_length;
 
-    RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, 64, ctx->stream));
     const bool old = o.estimator == RT_EST_OLD_RECURSIVE;
     const bool st = o.collect_stats != 0;
     int trav = o.traversal;
@@ -257,144 +320,211 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     P.force_replay = trav == RT_TRAV_FAST_REPLAY ? 1 : 0;
     // RT_TRAV_FAST: lane re-fill pays when walks are long and their fetches miss the L2 -- scenes whose fast tree and
     // triangle positions exceed the L2s; smaller scenes take k_path with the noted primitive tests.
-    const bool refill = trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && ctx->scene_bytes > kRefillSceneBytes);
+    pl.refill = trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && ctx->scene_bytes > kRefillSceneBytes);
     // ... among those, the flat scene in slices (measured +5 %; the sphere scene loses 7 % in slices)
-    const bool sliced = trav == RT_TRAV_FAST_SLICED || (trav == RT_TRAV_FAST && !refill && !old);
-    const bool queued = trav == RT_TRAV_FAST_QUEUED || (trav == RT_TRAV_FAST && !refill && !sliced);
-    if (trav == RT_TRAV_FAST_QUEUED || trav == RT_TRAV_FAST_INLINE || trav == RT_TRAV_FAST_SLICED)
+    pl.sliced = trav == RT_TRAV_FAST_SLICED || (trav == RT_TRAV_FAST && !pl.refill && !old);
+    pl.queued = trav == RT_TRAV_FAST_QUEUED || (trav == RT_TRAV_FAST && !pl.refill && !pl.sliced);
+    if (trav == RT_TRAV_FAST_QUEUED || trav == RT_TRAV_FAST_INLINE || trav == RT_TRAV_FAST_SLICED || trav == RT_TRAV_FAST_REFILL)
         trav = RT_TRAV_FAST;
-    if (trav == RT_TRAV_FAST_REFILL)
-        trav = RT_TRAV_FAST;
-    const int walk = trav == RT_TRAV_WAVE ? WALK_WAVE : (trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY) ? WALK_FAST
-                     : trav == RT_TRAV_BRUTE                                                               ? WALK_BRUTE
-                                                                                                           : WALK_LANE;
+    pl.walk = trav == RT_TRAV_WAVE ? WALK_WAVE : (trav == RT_TRAV_FAST || trav == RT_TRAV_FAST_REPLAY) ? WALK_FAST
+              : trav == RT_TRAV_BRUTE                                                               ? WALK_BRUTE
+                                                                                                    : WALK_LANE;
     P.wave_min_rays = o.traversal == RT_TRAV_WAVE ? 0u : 65536u;
-    const int variant = (trav == RT_TRAV_NESTED ? 0 : 4) + (old ? 2 : 0) + (st ? 1 : 0);
-    const uint32_t full_grid = (uint32_t)ctx->num_cus * (uint32_t)ctx->blocks_per_cu[variant + (variant >= 4 ? 4 * (walk == WALK_BRUTE ? WALK_LANE : walk) : 0)];
+    pl.nested = trav == RT_TRAV_NESTED;
+    pl.variant = (pl.nested ? 0 : 4) + (old ? 2 : 0) + (st ? 1 : 0);
+    pl.full_grid = (uint32_t)ctx->num_cus * (uint32_t)ctx->blocks_per_cu[pl.variant];
+    pl.npix = (size_t)W * (size_t)H;
+    pl.items_per_sample = (size_t)P.n_my_tiles * 64;
+    pl.levels = old ? o.bounce_limit + 1 : (o.bounce_limit > 1 ? o.bounce_limit : 1);
+    if (pl.sliced) { // rounds, not bounce levels: a walk may take several; the last launch finishes whatever is left
+        pl.levels += kSliceExtraRounds;
+        if (pl.levels > kMaxLevels - 1)
+            pl.levels = kMaxLevels - 1;
+    }
+    P.slice = kSlice;
+    P.tail_rays = kTailRays;
+    pl.rec4 = pl.sliced ? 6 : 4;
+    P.npix = (uint32_t)pl.npix;
+    pl.W = W;
+    pl.H = H;
+    pl.first = first;
+    pl.count = count;
+    return RT_OK;
+}
+
+// Samples per chunk: as many as `max_items` pixel samples allow (the tail of deep bounces is paid once per chunk), and
+// few enough that the colour slot s * npix + pixel of every sample stays a 32-bit number.
+int chunk_samples(const Plan &pl, size_t max_items) {
+    int S = pl.count < kChunkSamples ? pl.count : kChunkSamples;
+    if (pl.items_per_sample > 0 && (size_t)S * pl.items_per_sample > max_items)
+        S = (int)(max_items / pl.items_per_sample);
+    if ((size_t)S * pl.npix > 0xFFFFFFFFull)
+        S = (int)(0xFFFFFFFFull / pl.npix);
+    if (S < 1)
+        S = 1;
+    return S;
+}
+
+int launch_nested(rt_ctx *ctx, const Plan &pl, hipStream_t stream) {
+    const KParams &P = pl.P;
+    RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, 64, stream));
+    uint32_t blocks = pl.full_grid;
+    if (blocks > (P.n_my_tiles + 3) / 4)
+        blocks = (P.n_my_tiles + 3) / 4;
+    if (blocks < 1)
+        blocks = 1;
+    dim3 grid(blocks), block(256);
+    switch (pl.variant) {
+    case 0: hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, stream, P); break;
+    case 1: hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, stream, P); break;
+    case 2: hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, stream, P); break;
+    default: hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, stream, P); break;
+    }
+    RT_HIP_CHECK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+// One chunk of the wavefront tracer on `stream`, in workspace `ws`: samples pl.first + done .. + s_now - 1 of every owned
+// pixel, one launch per bounce level (or round), their colours left in ws.colors.  The caller folds them.
+int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t stream, int done, int s_now, KParams &P) {
+    P = pl.P;
+    const int levels = pl.levels;
+    RT_HIP_CHECK(ctx, hipMemsetAsync(ws.levels, 0, (size_t)(levels + 1) * kSubQueues * 32 * sizeof(unsigned int), stream));
+    P.colors = ws.colors;
+    P.S = s_now;
+    P.div_per_tile = make_fastdiv(64u * (uint32_t)s_now);
+    P.chunk_first = pl.first + done;
+    P.n_items = (uint32_t)((size_t)s_now * pl.items_per_sample);
+    P.sub_cap = (((P.n_items + 63u) / 64u) / (uint32_t)kSubQueues + 66u) * 64u;
+    const bool sliced = pl.sliced, queued = pl.queued, refill = pl.refill;
+    const int walk = pl.walk;
+    dim3 block(256);
+    for (int level = 0; level < levels; level++) {
+        P.level = level;
+        P.tail = level == levels - 1 ? 1 : 0;
+        P.q_in = ws.q[level & 1];
+        P.q_out = ws.q[(level + 1) & 1];
+        P.sub_in = ws.levels + (size_t)level * kSubQueues * 32;
+        P.sub_cursor = ws.levels + (size_t)level * kSubQueues * 32 + 1;
+        P.sub_out = ws.levels + (size_t)(level + 1) * kSubQueues * 32;
+        uint32_t blocks = pl.full_grid;
+        if (level == 0 && blocks > (P.n_items / 64 + 3) / 4)
+            blocks = (P.n_items / 64 + 3) / 4;
+        if (blocks < 1)
+            blocks = 1;
+        dim3 grid(blocks);
+        // wave-synchronous walk: register allocation capped at 64 VGPRs (8 waves per SIMD hide the scalar
+        // fetch latency; the spills land in the shading code, which runs once per ray); the others: uncapped
+#define RT_LAUNCH_PATH(OLD_, STATS_)                                                                                  \
+    do {                                                                                                              \
+        if (walk == WALK_FAST && sliced) hipLaunchKernelGGL((k_sliced<OLD_, STATS_>), grid, block, 0, stream, P);     \
+        else if (walk == WALK_FAST && queued) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_QUEUED>), grid, block, 0, stream, P); \
+        else if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, 0, stream, P); \
+        else if (walk == WALK_FAST && refill) hipLaunchKernelGGL((k_refill<OLD_, STATS_>), grid, block, 0, stream, P); \
+        else if (walk == WALK_FAST) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_FAST>), grid, block, 0, stream, P); \
+        else if (walk == WALK_BRUTE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_BRUTE>), grid, block, 0, stream, P); \
+        else hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_LANE>), grid, block, 0, stream, P);                         \
+    } while (0)
+        switch (pl.variant) {
+        case 4: RT_LAUNCH_PATH(false, false); break;
+        case 5: RT_LAUNCH_PATH(false, true); break;
+        case 6: RT_LAUNCH_PATH(true, false); break;
+        default: RT_LAUNCH_PATH(true, true); break;
+        }
+#undef RT_LAUNCH_PATH
+        RT_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return RT_OK;
+}
+
+int launch_fold(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t stream, const KParams &P) {
+    hipLaunchKernelGGL(k_fold, dim3((unsigned)((pl.npix + 255) / 256)), dim3(256), 0, stream, P.image, ws.colors, (uint32_t)pl.npix,
+                       pl.W, P.tiles_x, P.tile_rank, P.tile_world, P.chunk_first, P.S);
+    RT_HIP_CHECK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+// Gives a pipe's workspace room for chunks of `need_colors` colours and queues of `need_q4` float4 (allocates; the pipe's
+// stream is drained first when buffers have to be replaced).
+int ensure_workspace(rt_ctx *ctx, rt_ctx::Pipe &pp, size_t need_colors, size_t need_q4) {
+    Workspace &ws = pp.ws;
+    if (need_colors <= ws.colors_cap && need_q4 <= ws.q_cap)
+        return RT_OK;
+    RT_HIP_CHECK(ctx, hipStreamSynchronize(pp.stream));
+    if (need_colors < ws.colors_cap)
+        need_colors = ws.colors_cap;
+    if (need_q4 < ws.q_cap)
+        need_q4 = ws.q_cap;
+    unsigned int *levels = ws.levels;
+    ws.levels = nullptr;
+    free_workspace(ws);
+    ws.levels = levels;
+    RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.colors, (need_colors ? need_colors : 1) * sizeof(float4)));
+    RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.q[0], (need_q4 ? need_q4 : 1) * sizeof(float4)));
+    RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.q[1], (need_q4 ? need_q4 : 1) * sizeof(float4)));
+    ws.colors_cap = need_colors;
+    ws.q_cap = need_q4;
+    return RT_OK;
+}
+
+int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim) {
+    Plan pl;
+    {
+        const int prc = make_plan(ctx, W, H, first, count, d_img, d_prim, pl);
+        if (prc != RT_OK)
+            return prc;
+    }
     if (ctx->pending == ctx->events.size()) {
         hipEvent_t a, b;
         RT_HIP_CHECK(ctx, hipEventCreate(&a));
         RT_HIP_CHECK(ctx, hipEventCreate(&b));
         ctx->events.emplace_back(a, b);
     }
-    dim3 block(256);
-    if (trav == RT_TRAV_NESTED) {
+    ctx->counted = true;
+    if (pl.nested) {
         {
             const int jrc = join_pipes(ctx); // earlier pipelined calls may still be folding into this image
             if (jrc != RT_OK)
                 return jrc;
         }
-        uint32_t blocks = full_grid;
-        if (blocks > (P.n_my_tiles + 3) / 4)
-            blocks = (P.n_my_tiles + 3) / 4;
-        if (blocks < 1)
-            blocks = 1;
-        dim3 grid(blocks);
         RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
-        switch (variant) {
-        case 0: hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, ctx->stream, P); break;
-        case 1: hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, ctx->stream, P); break;
-        case 2: hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, ctx->stream, P); break;
-        default: hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, ctx->stream, P); break;
-        }
-        RT_HIP_CHECK(ctx, hipGetLastError());
+        const int nrc = launch_nested(ctx, pl, ctx->stream);
+        if (nrc != RT_OK)
+            return nrc;
         RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].second, ctx->stream));
         ctx->pending++;
         return RT_OK;
     }
-    // ---- wavefront: samples in chunks of S; per chunk one k_path launch per bounce level, then k_fold ----
-    const size_t npix = (size_t)W * (size_t)H;
-    const size_t items_per_sample = (size_t)P.n_my_tiles * 64;
-    int S = count < kChunkSamples ? count : kChunkSamples;
-    if (items_per_sample > 0 && (size_t)S * items_per_sample > kMaxItems)
-        S = (int)(kMaxItems / items_per_sample);
-    if (S < 1)
-        S = 1;
-    // queue capacity: a sub-queue of the next level receives the continuing paths (at most 64) of every 64th batch of
-    // level 0, or of every 64th batch of each of this level's 64 sub-queues; no level has more batches than level 0
-    // has plus one partial batch per sub-queue, so (n_batches / 64 + 66) * 64 records per sub-queue always suffice
-    const size_t need_colors = (size_t)S * npix, need_q = (size_t)S * items_per_sample + (size_t)kSubQueues * 66 * 64;
-    int levels = old ? o.bounce_limit + 1 : (o.bounce_limit > 1 ? o.bounce_limit : 1);
-    if (sliced) { // rounds, not bounce levels: a walk may take several; the last launch finishes whatever is left
-        levels += kSliceExtraRounds;
-        if (levels > kMaxLevels - 1)
-            levels = kMaxLevels - 1;
-    }
-    P.slice = kSlice;
-    P.tail_rays = kTailRays;
-    const size_t rec4 = sliced ? 6 : 4; // float4 per queue record
-    P.npix = (uint32_t)npix;
+    // ---- wavefront: samples in chunks of S; per chunk one launch per bounce level (or round), then k_fold ----
+    const int S = chunk_samples(pl, kMaxItems);
+    const size_t need_colors = (size_t)S * pl.npix, need_q4 = queue_records((size_t)S * pl.items_per_sample) * pl.rec4;
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     hipStream_t last_stream = ctx->stream;
-    for (int done = 0; done < count || (count == 0 && done == 0); done += S) {
+    for (int done = 0; done < count; done += S) {
         const int s_now = count - done < S ? count - done : S;
-        if (s_now <= 0)
-            break;
         rt_ctx::Pipe &pp = ctx->pipes[ctx->next_pipe];
         ctx->next_pipe ^= 1;
-        if (need_colors > pp.colors_cap || need_q * rec4 > pp.q_cap) {
-            RT_HIP_CHECK(ctx, hipStreamSynchronize(pp.stream));
-            if (pp.d_colors) (void)hipFree(pp.d_colors);
-            if (pp.d_q[0]) (void)hipFree(pp.d_q[0]);
-            if (pp.d_q[1]) (void)hipFree(pp.d_q[1]);
-            pp.d_colors = pp.d_q[0] = pp.d_q[1] = nullptr;
-            pp.colors_cap = pp.q_cap = 0;
-            RT_HIP_CHECK(ctx, hipMalloc((void **)&pp.d_colors, need_colors * sizeof(float4)));
-            RT_HIP_CHECK(ctx, hipMalloc((void **)&pp.d_q[0], (need_q ? need_q : 1) * rec4 * sizeof(float4)));
-            RT_HIP_CHECK(ctx, hipMalloc((void **)&pp.d_q[1], (need_q ? need_q : 1) * rec4 * sizeof(float4)));
-            pp.colors_cap = need_colors;
-            pp.q_cap = need_q * rec4;
+        {
+            const int wrc = ensure_workspace(ctx, pp, need_colors, need_q4);
+            if (wrc != RT_OK)
+                return wrc;
         }
         RT_HIP_CHECK(ctx, hipStreamWaitEvent(pp.stream, ctx->ev_start, 0));
-        RT_HIP_CHECK(ctx, hipMemsetAsync(pp.d_levels, 0, (size_t)(levels + 1) * kSubQueues * 32 * sizeof(unsigned int), pp.stream));
-        P.colors = pp.d_colors;
-        P.S = s_now;
-        P.div_per_tile = make_fastdiv(64u * (uint32_t)s_now);
-        P.chunk_first = first + done;
-        P.n_items = (uint32_t)((size_t)s_now * items_per_sample);
-        P.sub_cap = (((P.n_items + 63u) / 64u) / (uint32_t)kSubQueues + 66u) * 64u;
-        for (int level = 0; level < levels; level++) {
-            P.level = level;
-            P.tail = level == levels - 1 ? 1 : 0;
-            P.q_in = pp.d_q[level & 1];
-            P.q_out = pp.d_q[(level + 1) & 1];
-            P.sub_in = pp.d_levels + (size_t)level * kSubQueues * 32;
-            P.sub_cursor = pp.d_levels + (size_t)level * kSubQueues * 32 + 1;
-            P.sub_out = pp.d_levels + (size_t)(level + 1) * kSubQueues * 32;
-            uint32_t blocks = full_grid;
-            if (level == 0 && blocks > (P.n_items / 64 + 3) / 4)
-                blocks = (P.n_items / 64 + 3) / 4;
-            if (blocks < 1)
-                blocks = 1;
-            dim3 grid(blocks);
-            // wave-synchronous walk: register allocation capped at 64 VGPRs (8 waves per SIMD hide the scalar
-            // fetch latency; the spills land in the shading code, which runs once per ray); the others: uncapped
-#define RT_LAUNCH_PATH(OLD_, STATS_)                                                                                  \
-    do {                                                                                                              \
-        if (walk == WALK_FAST && sliced) hipLaunchKernelGGL((k_sliced<OLD_, STATS_>), grid, block, 0, pp.stream, P); \
-        else if (walk == WALK_FAST && queued) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_QUEUED>), grid, block, 0, pp.stream, P); \
-        else if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, 0, pp.stream, P); \
-        else if (walk == WALK_FAST && refill) hipLaunchKernelGGL((k_refill<OLD_, STATS_>), grid, block, 0, pp.stream, P); \
-        else if (walk == WALK_FAST) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_FAST>), grid, block, 0, pp.stream, P); \
-        else if (walk == WALK_BRUTE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_BRUTE>), grid, block, 0, pp.stream, P); \
-        else hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_LANE>), grid, block, 0, pp.stream, P);                       \
-    } while (0)
-            switch (variant) {
-            case 4: RT_LAUNCH_PATH(false, false); break;
-            case 5: RT_LAUNCH_PATH(false, true); break;
-            case 6: RT_LAUNCH_PATH(true, false); break;
-            default: RT_LAUNCH_PATH(true, true); break;
-            }
-#undef RT_LAUNCH_PATH
-            RT_HIP_CHECK(ctx, hipGetLastError());
+        KParams P;
+        {
+            const int crc = launch_chunk(ctx, pl, pp.ws, pp.stream, done, s_now, P);
+            if (crc != RT_OK)
+                return crc;
         }
         // the running mean takes the samples in order: this fold waits for the one before it, whichever pipe ran it
         if (ctx->last_fold != nullptr && ctx->last_fold != pp.done)
             RT_HIP_CHECK(ctx, hipStreamWaitEvent(pp.stream, ctx->last_fold, 0));
-        hipLaunchKernelGGL(k_fold, dim3((unsigned)((npix + 255) / 256)), block, 0, pp.stream, d_img, pp.d_colors,
-                           (uint32_t)npix, W, P.tiles_x, o.tile_rank, o.tile_world, P.chunk_first, s_now);
-        RT_HIP_CHECK(ctx, hipGetLastError());
+        {
+            const int frc = launch_fold(ctx, pl, pp.ws, pp.stream, P);
+            if (frc != RT_OK)
+                return frc;
+        }
         RT_HIP_CHECK(ctx, hipEventRecord(pp.done, pp.stream));
         pp.used = true;
         ctx->last_fold = pp.done;
@@ -412,6 +542,18 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     return RT_OK;
 }
 
+void add_stats(rt_stats &a, const rt_stats &b) {
+    a.rays += b.rays;
+    a.box_tests += b.box_tests;
+    a.tri_tests += b.tri_tests;
+    a.sph_tests += b.sph_tests;
+    a.tri_hits += b.tri_hits;
+    a.replays += b.replays;
+    a.kernel_ms = a.kernel_ms > b.kernel_ms ? a.kernel_ms : b.kernel_ms; // devices work side by side
+    a.kernel_ms_sum = a.kernel_ms_sum > b.kernel_ms_sum ? a.kernel_ms_sum : b.kernel_ms_sum;
+    a.launches = a.launches > b.launches ? a.launches : b.launches;
+}
+
 int sync_and_stats(rt_ctx *ctx, rt_stats *stats) {
     {
         const int src = sync_all(ctx);
@@ -420,7 +562,7 @@ int sync_and_stats(rt_ctx *ctx, rt_stats *stats) {
     }
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        if (ctx->pending > 0) {
+        if (ctx->counted) {
             unsigned long long slots[kCounterSlots * kCounterStride], h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             RT_HIP_CHECK(ctx, hipMemcpy(slots, ctx->d_counters, sizeof(slots), hipMemcpyDeviceToHost));
             for (int sl = 0; sl < kCounterSlots; sl++)
@@ -434,6 +576,8 @@ int sync_and_stats(rt_ctx *ctx, rt_stats *stats) {
             stats->sph_tests = h[3];
             stats->tri_hits = h[4];
             stats->replays = h[5];
+        }
+        if (ctx->pending > 0) {
             float ms = 0.f, sum = 0.f;
             for (size_t i = 0; i < ctx->pending; i++) {
                 RT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
@@ -446,13 +590,290 @@ int sync_and_stats(rt_ctx *ctx, rt_stats *stats) {
             stats->launches = (uint32_t)ctx->pending;
         }
     }
-    if (ctx->pending > 0) // counters run from one sync to the next
+    if (ctx->counted) // counters run from one sync to the next
         RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, kCounterSlots * kCounterStride * sizeof(unsigned long long), ctx->stream));
     ctx->pending = 0;
+    ctx->counted = false;
+    return RT_OK;
+}
+
+// (Re)allocates the context's own running-mean image for a W x H frame; a new size starts from zero
+// (CPUImageData::resize, Renderer/TraceMethods.hpp:31-36, as TracerAsync::resize + resetSamples use it).
+int ensure_image(rt_ctx *ctx, int width, int height) {
+    const size_t px = (size_t)width * (size_t)height;
+    if (width != ctx->img_w || height != ctx->img_h || !ctx->d_image) {
+        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_image) (void)hipFree(ctx->d_image);
+        if (ctx->d_primary) (void)hipFree(ctx->d_primary);
+        ctx->d_image = nullptr;
+        ctx->d_primary = nullptr;
+        ctx->img_w = ctx->img_h = 0;
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_image, px * sizeof(float4)));
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_primary, px * sizeof(uint32_t)));
+        ctx->img_w = width;
+        ctx->img_h = height;
+        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_image, 0, px * sizeof(float4), ctx->stream));
+    }
     return RT_OK;
 }
 
 #include "scene_layout.hpp"
+
+int upload_layout(rt_ctx *ctx, const SceneLayout &L) {
+    RT_ON_DEVICE(ctx);
+    {
+        const int src = sync_all(ctx); // nothing may still be walking the old scene
+        if (src != RT_OK)
+            return src;
+    }
+    free_scene(ctx);
+    int rc;
+    if ((rc = upload(ctx, &ctx->d_nodes, L.dn)) != RT_OK || (rc = upload(ctx, &ctx->d_fnodes, L.fn)) != RT_OK ||
+        (rc = upload(ctx, &ctx->d_tri_pos, L.tp)) != RT_OK || (rc = upload(ctx, &ctx->d_tri_nrm, L.tn)) != RT_OK ||
+        (rc = upload(ctx, &ctx->d_spheres, L.sp)) != RT_OK || (rc = upload(ctx, &ctx->d_mats, L.mt)) != RT_OK) {
+        free_scene(ctx);
+        return rc;
+    }
+    ctx->expected_visits = L.expected_visits;
+    ctx->fast_exact = L.nested;
+    ctx->scene_bytes = (L.fn.size() + L.tp.size()) * sizeof(float4);
+    ctx->n_nodes = L.n_ref;
+    ctx->n_fnodes = L.n_fast;
+    ctx->has_scene = true;
+    return RT_OK;
+}
+
+bool options_ok(const rt_options *opt) {
+    return !(opt->bounce_limit < 0 || opt->bounce_limit > kMaxLevels - 2 || opt->tile_world < 1 || opt->tile_rank < 0 ||
+             opt->tile_rank >= opt->tile_world || (opt->estimator != RT_EST_SD_LOOP && opt->estimator != RT_EST_OLD_RECURSIVE) ||
+             opt->traversal < 0 || opt->traversal > RT_TRAV_FAST_SLICED ||
+             (opt->multi_split != RT_SPLIT_TILE && opt->multi_split != RT_SPLIT_SAMPLE));
+}
+
+void destroy_single(rt_ctx *ctx) {
+    if (!ctx)
+        return;
+    DeviceGuard g(ctx->device);
+    for (auto &pp : ctx->pipes)
+        if (pp.stream)
+            (void)hipStreamSynchronize(pp.stream);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    if (ctx->d_image) (void)hipFree(ctx->d_image);
+    if (ctx->d_primary) (void)hipFree(ctx->d_primary);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    for (auto &pp : ctx->pipes) {
+        if (pp.ws.levels) (void)hipFree(pp.ws.levels);
+        pp.ws.levels = nullptr;
+        free_workspace(pp.ws);
+        if (pp.done) (void)hipEventDestroy(pp.done);
+        if (pp.stream) (void)hipStreamDestroy(pp.stream);
+    }
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    for (auto &e : ctx->events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    for (float4 *p : ctx->peer_img)
+        if (p) (void)hipFree(p);
+    for (uint32_t *p : ctx->peer_prim)
+        if (p) (void)hipFree(p);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int create_single(rt_ctx **out, int device) {
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+        return RT_ERR_NO_DEVICE;
+    rt_ctx *ctx = new rt_ctx();
+    ctx->device = device;
+    std::memset(&ctx->cam, 0, sizeof(ctx->cam));
+    ctx->opt = rt_options{4, RT_EST_SD_LOOP, 1u, 0.001f, 0, 1, 0, 0u, RT_TRAV_AUTO, RT_SPLIT_TILE};
+    DeviceGuard g(device);
+    auto bail = [&](const char *what) { // whatever exists by now is released the way rt_destroy releases it
+        std::fprintf(stderr, "rt_create: %s failed\n", what);
+        destroy_single(ctx);
+        return RT_ERR_HIP;
+    };
+    if (g.rc != hipSuccess) return bail("hipSetDevice");
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
+    ctx->own_stream = true;
+    if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void **)&ctx->d_counters, kCounterSlots * kCounterStride * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc");
+    if (hipMemset(ctx->d_counters, 0, kCounterSlots * kCounterStride * sizeof(unsigned long long)) != hipSuccess) return bail("hipMemset");
+    if (hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
+    for (auto &pp : ctx->pipes) {
+        if (hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
+        if (hipEventCreateWithFlags(&pp.done, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
+        if (hipMalloc((void **)&pp.ws.levels, kLevelWords * sizeof(unsigned int)) != hipSuccess) return bail("hipMalloc");
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail("hipGetDeviceProperties");
+    ctx->num_cus = prop.multiProcessorCount;
+    occupancy<0, false, false>(&ctx->blocks_per_cu[0]);
+    occupancy<0, false, true>(&ctx->blocks_per_cu[1]);
+    occupancy<0, true, false>(&ctx->blocks_per_cu[2]);
+    occupancy<0, true, true>(&ctx->blocks_per_cu[3]);
+    for (int v = 4; v < 8; v++)
+        occupancy<1, false, false>(&ctx->blocks_per_cu[v]);
+    *out = ctx;
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------ several devices behind one context
+// rt_create_multi: kid r renders its share of every call on its own device -- its tiles of the frame (RT_SPLIT_TILE:
+// tile k belongs to kid k % n) or its samples of the whole frame (RT_SPLIT_SAMPLE) -- into its own image; one host
+// thread per device issues the work and waits for it; the frames then travel to the first device of the list
+// (hipMemcpyPeerAsync over xGMI, one landing buffer per kid) and are put together there: owned tiles copied, or the
+// per-kid means added with weights samples_r / samples.  The scene is replicated on every device.
+int multi_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_out, uint32_t *d_prim, bool zero_out) {
+    const int n = (int)ctx->kids.size();
+    if (!ctx->has_camera)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "camera not set");
+    if (W <= 0 || H <= 0 || first < 1 || count < 0 || (long long)W * H > 0x7FFFFFFFll)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad width/height/sample range");
+    const size_t px = (size_t)W * (size_t)H;
+    const bool by_sample = ctx->opt.multi_split == RT_SPLIT_SAMPLE;
+    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // the previous call's gather may still be reading the kids' frames
+    if (first == 1)
+        for (int &s : ctx->kid_samples)
+            s = 0;
+    // landing buffers on the first device
+    if (px > ctx->peer_cap) {
+        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int r = 1; r < n; r++) {
+            if (ctx->peer_img[r]) (void)hipFree(ctx->peer_img[r]);
+            if (ctx->peer_prim[r]) (void)hipFree(ctx->peer_prim[r]);
+            ctx->peer_img[r] = nullptr;
+            ctx->peer_prim[r] = nullptr;
+        }
+        ctx->peer_cap = 0;
+        for (int r = 1; r < n; r++) {
+            RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->peer_img[r], px * sizeof(float4)));
+            RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->peer_prim[r], px * sizeof(uint32_t)));
+        }
+        ctx->peer_cap = px;
+    }
+    // shares
+    std::vector<int> share(n, 0), start(n, 0);
+    for (int r = 0, at = 0; r < n; r++) {
+        share[r] = by_sample ? count / n + (r < count % n ? 1 : 0) : count;
+        start[r] = by_sample ? at : 0;
+        at += share[r];
+    }
+    std::vector<int> rcs(n, RT_OK);
+    auto work = [&](int r) {
+        rt_ctx *k = ctx->kids[r];
+        std::lock_guard<std::mutex> lock(k->mu);
+        DeviceGuard g(k->device);
+        if (g.rc != hipSuccess) {
+            rcs[r] = fail(k, RT_ERR_HIP, "hipSetDevice failed");
+            return;
+        }
+        rt_options o = ctx->opt;
+        int kfirst = first;
+        if (by_sample) { // the kid keeps a running mean of ITS samples: local numbering, the global index goes into the RNG key
+            kfirst = ctx->kid_samples[r] + 1;
+            o.sample_offset = ctx->opt.sample_offset + (uint32_t)(first + start[r] - kfirst);
+        } else {
+            o.tile_rank = ctx->opt.tile_rank + r * ctx->opt.tile_world;
+            o.tile_world = ctx->opt.tile_world * n;
+        }
+        k->opt = o;
+        k->cam = ctx->cam;
+        k->has_camera = true;
+        int rc = ensure_image(k, W, H);
+        if (rc == RT_OK && kfirst == 1)
+            rc = hipMemsetAsync(k->d_image, 0, px * sizeof(float4), k->stream) == hipSuccess ? RT_OK : fail(k, RT_ERR_HIP, "hipMemsetAsync failed");
+        const bool want_prim = d_prim != nullptr && (!by_sample || r == 0);
+        if (rc == RT_OK && want_prim)
+            rc = hipMemsetAsync(k->d_primary, 0xFF, px * sizeof(uint32_t), k->stream) == hipSuccess ? RT_OK : fail(k, RT_ERR_HIP, "hipMemsetAsync failed");
+        if (rc == RT_OK && share[r] > 0)
+            rc = launch_trace(k, W, H, kfirst, share[r], k->d_image, want_prim ? k->d_primary : nullptr);
+        if (rc == RT_OK)
+            rc = sync_all(k);
+        rcs[r] = rc;
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int r = 1; r < n; r++)
+            threads.emplace_back(work, r);
+        work(0);
+        for (auto &t : threads)
+            t.join();
+    }
+    for (int r = 0; r < n; r++)
+        if (rcs[r] != RT_OK) {
+            std::string msg;
+            {
+                std::lock_guard<std::mutex> g(ctx->kids[r]->err_mu);
+                msg = ctx->kids[r]->err;
+            }
+            return fail(ctx, rcs[r], "device " + std::to_string(ctx->kids[r]->device) + ": " + msg);
+        }
+    if (by_sample)
+        for (int r = 0; r < n; r++)
+            ctx->kid_samples[r] += share[r];
+    // gather on the first device
+    if (zero_out)
+        RT_HIP_CHECK(ctx, hipMemsetAsync(d_out, 0, px * sizeof(float4), ctx->stream));
+    if (d_prim != nullptr)
+        RT_HIP_CHECK(ctx, hipMemsetAsync(d_prim, 0xFF, px * sizeof(uint32_t), ctx->stream));
+    int total = 0;
+    for (int r = 0; r < n; r++)
+        total += ctx->kid_samples[r];
+    const dim3 grid((unsigned)((px + 255) / 256)), block(256);
+    bool first_term = true;
+    for (int r = 0; r < n; r++) {
+        rt_ctx *k = ctx->kids[r];
+        const float4 *src = k->d_image;
+        const uint32_t *psrc = k->d_primary;
+        const bool want_prim = d_prim != nullptr && (!by_sample || r == 0);
+        if (r > 0) {
+            RT_HIP_CHECK(ctx, hipMemcpyPeerAsync(ctx->peer_img[r], ctx->device, k->d_image, k->device, px * sizeof(float4), ctx->stream));
+            src = ctx->peer_img[r];
+            if (want_prim) {
+                RT_HIP_CHECK(ctx, hipMemcpyPeerAsync(ctx->peer_prim[r], ctx->device, k->d_primary, k->device, px * sizeof(uint32_t), ctx->stream));
+                psrc = ctx->peer_prim[r];
+            }
+        }
+        if (by_sample) {
+            if (ctx->kid_samples[r] == 0)
+                continue;
+            const float w = (float)ctx->kid_samples[r] / (float)total;
+            hipLaunchKernelGGL(k_add_weighted, grid, block, 0, ctx->stream, d_out, src, (uint32_t)px, w, first_term ? 1 : 0);
+            first_term = false;
+            if (want_prim)
+                RT_HIP_CHECK(ctx, hipMemcpyAsync(d_prim, psrc, px * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            hipLaunchKernelGGL(k_take_tiles, grid, block, 0, ctx->stream, d_out, src, want_prim ? d_prim : nullptr, psrc, (uint32_t)px, W,
+                               (W + 7) / 8, ctx->opt.tile_rank + r * ctx->opt.tile_world, ctx->opt.tile_world * n);
+        }
+        RT_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return RT_OK;
+}
+
+int multi_sync(rt_ctx *ctx, rt_stats *stats) {
+    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats)
+        std::memset(stats, 0, sizeof(*stats));
+    for (rt_ctx *k : ctx->kids) {
+        std::lock_guard<std::mutex> lock(k->mu);
+        DeviceGuard g(k->device);
+        rt_stats s;
+        const int rc = sync_and_stats(k, &s);
+        if (rc != RT_OK)
+            return fail(ctx, rc, "device " + std::to_string(k->device) + ": sync failed");
+        if (stats)
+            add_stats(*stats, s);
+    }
+    return RT_OK;
+}
 
 } // namespace
 
@@ -469,91 +890,66 @@ void rt_free_host(void *ptr) {
         (void)hipHostFree(ptr);
 }
 
-const char *rt_version(void) { return "rt_hip 0.1 gfx950"; }
+const char *rt_version(void) { return "rt_hip 0.2 gfx950"; }
 
 int rt_create(rt_ctx **out, int device) {
     if (!out)
         return RT_ERR_INVALID_ARGUMENT;
+    return create_single(out, device);
+}
+
+int rt_create_multi(rt_ctx **out, const int *device_ids, int n_devices) {
+    if (!out)
+        return RT_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
-        return RT_ERR_NO_DEVICE;
-    rt_ctx *ctx = new rt_ctx();
-    ctx->device = device;
-    std::memset(&ctx->cam, 0, sizeof(ctx->cam));
-    ctx->opt = rt_options{4, RT_EST_SD_LOOP, 1u, 0.001f, 0, 1, 0, 0u, RT_TRAV_AUTO};
-    auto bail = [&](const char *what) {
-        std::fprintf(stderr, "rt_create: %s failed\n", what);
-        delete ctx;
-        return RT_ERR_HIP;
-    };
-    if (hipSetDevice(device) != hipSuccess) return bail("hipSetDevice");
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
-    ctx->own_stream = true;
-    if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) return bail("hipMalloc");
-    if (hipMalloc((void **)&ctx->d_counters, kCounterSlots * kCounterStride * sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc");
-    if (hipMemset(ctx->d_counters, 0, kCounterSlots * kCounterStride * sizeof(unsigned long long)) != hipSuccess) return bail("hipMemset");
-    if (hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
-    for (auto &pp : ctx->pipes) {
-        if (hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
-        if (hipEventCreateWithFlags(&pp.done, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
-        if (hipMalloc((void **)&pp.d_levels, (size_t)(kMaxLevels + 1) * kSubQueues * 32 * sizeof(unsigned int)) != hipSuccess) return bail("hipMalloc");
+    if (!device_ids || n_devices < 1 || n_devices > 64)
+        return RT_ERR_INVALID_ARGUMENT;
+    if (n_devices == 1)
+        return create_single(out, device_ids[0]);
+    rt_ctx *root = nullptr;
+    int rc = create_single(&root, device_ids[0]);
+    if (rc != RT_OK)
+        return rc;
+    root->peer_img.assign(n_devices, nullptr);
+    root->peer_prim.assign(n_devices, nullptr);
+    root->kid_samples.assign(n_devices, 0);
+    for (int r = 0; r < n_devices; r++) {
+        rt_ctx *k = nullptr;
+        rc = create_single(&k, device_ids[r]);
+        if (rc != RT_OK) {
+            for (rt_ctx *made : root->kids)
+                destroy_single(made);
+            root->kids.clear();
+            destroy_single(root);
+            return rc;
+        }
+        root->kids.push_back(k);
     }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail("hipGetDeviceProperties");
-    ctx->num_cus = prop.multiProcessorCount;
-    occupancy<0, false, false>(&ctx->blocks_per_cu[0]);
-    occupancy<0, false, true>(&ctx->blocks_per_cu[1]);
-    occupancy<0, true, false>(&ctx->blocks_per_cu[2]);
-    occupancy<0, true, true>(&ctx->blocks_per_cu[3]);
-    occupancy<1, false, false>(&ctx->blocks_per_cu[4]);
-    occupancy<1, false, true>(&ctx->blocks_per_cu[5]);
-    occupancy<1, true, false>(&ctx->blocks_per_cu[6]);
-    occupancy<1, true, true>(&ctx->blocks_per_cu[7]);
-    occupancy<2, false, false>(&ctx->blocks_per_cu[8]);
-    occupancy<2, false, true>(&ctx->blocks_per_cu[9]);
-    occupancy<2, true, false>(&ctx->blocks_per_cu[10]);
-    occupancy<2, true, true>(&ctx->blocks_per_cu[11]);
-    occupancy<3, false, false>(&ctx->blocks_per_cu[12]);
-    occupancy<3, false, true>(&ctx->blocks_per_cu[13]);
-    occupancy<3, true, false>(&ctx->blocks_per_cu[14]);
-    occupancy<3, true, true>(&ctx->blocks_per_cu[15]);
-    *out = ctx;
+    *out = root;
     return RT_OK;
 }
+
+int rt_device_count(rt_ctx *ctx) { return !ctx ? 0 : ctx->kids.empty() ? 1 : (int)ctx->kids.size(); }
 
 void rt_destroy(rt_ctx *ctx) {
     if (!ctx)
         return;
-    (void)hipSetDevice(ctx->device);
-    for (auto &pp : ctx->pipes)
-        if (pp.stream)
-            (void)hipStreamSynchronize(pp.stream);
-    if (ctx->stream)
-        (void)hipStreamSynchronize(ctx->stream);
-    free_scene(ctx);
-    if (ctx->d_image) (void)hipFree(ctx->d_image);
-    if (ctx->d_primary) (void)hipFree(ctx->d_primary);
-    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
-    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-    for (auto &pp : ctx->pipes) {
-        if (pp.d_levels) (void)hipFree(pp.d_levels);
-        if (pp.d_colors) (void)hipFree(pp.d_colors);
-        if (pp.d_q[0]) (void)hipFree(pp.d_q[0]);
-        if (pp.d_q[1]) (void)hipFree(pp.d_q[1]);
-        if (pp.done) (void)hipEventDestroy(pp.done);
-        if (pp.stream) (void)hipStreamDestroy(pp.stream);
-    }
-    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-    for (auto &e : ctx->events) {
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
-    }
-    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
+    for (rt_ctx *k : ctx->kids)
+        destroy_single(k);
+    ctx->kids.clear();
+    destroy_single(ctx);
 }
 
-const char *rt_last_error(rt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char *rt_last_error(rt_ctx *ctx) {
+    static thread_local std::string copy; // stays valid for the calling thread whatever other threads do to the context
+    if (!ctx)
+        return "null context";
+    {
+        std::lock_guard<std::mutex> g(ctx->err_mu);
+        copy = ctx->err;
+    }
+    return copy.c_str();
+}
 
 int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt_tri *tris,
                     uint32_t n_tris, const rt_sphere *spheres, uint32_t n_spheres, const rt_material *mats,
@@ -568,27 +964,14 @@ int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_
         if (lrc != RT_OK)
             return fail(ctx, lrc, err);
     }
-    const std::vector<float4> &dn = L.dn, &fn = L.fn, &tp = L.tp, &tn = L.tn, &sp = L.sp, &mt = L.mt;
-    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    {
-        const int src = sync_all(ctx); // nothing may still be walking the old scene
-        if (src != RT_OK)
-            return src;
+    if (ctx->kids.empty())
+        return upload_layout(ctx, L);
+    for (rt_ctx *k : ctx->kids) { // replicated: every device walks its own copy
+        std::lock_guard<std::mutex> klock(k->mu);
+        const int rc = upload_layout(k, L);
+        if (rc != RT_OK)
+            return fail(ctx, rc, "device " + std::to_string(k->device) + ": " + rt_last_error(k));
     }
-    free_scene(ctx);
-    int rc;
-    if ((rc = upload(ctx, &ctx->d_nodes, dn)) != RT_OK || (rc = upload(ctx, &ctx->d_fnodes, fn)) != RT_OK ||
-        (rc = upload(ctx, &ctx->d_tri_pos, tp)) != RT_OK ||
-        (rc = upload(ctx, &ctx->d_tri_nrm, tn)) != RT_OK || (rc = upload(ctx, &ctx->d_spheres, sp)) != RT_OK ||
-        (rc = upload(ctx, &ctx->d_mats, mt)) != RT_OK) {
-        free_scene(ctx);
-        return rc;
-    }
-    ctx->expected_visits = L.expected_visits;
-    ctx->fast_exact = L.nested;
-    ctx->scene_bytes = (L.fn.size() + L.tp.size()) * sizeof(float4);
-    ctx->n_nodes = L.n_ref;
-    ctx->n_fnodes = L.n_fast;
     ctx->has_scene = true;
     return RT_OK;
 }
@@ -606,11 +989,44 @@ int rt_set_options(rt_ctx *ctx, const rt_options *opt) {
     if (!ctx || !opt)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    if (opt->bounce_limit < 0 || opt->bounce_limit > kMaxLevels - 2 || opt->tile_world < 1 || opt->tile_rank < 0 || opt->tile_rank >= opt->tile_world ||
-        (opt->estimator != RT_EST_SD_LOOP && opt->estimator != RT_EST_OLD_RECURSIVE) || opt->traversal < 0 ||
-        opt->traversal > RT_TRAV_FAST_SLICED)
+    if (!options_ok(opt))
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad options");
     ctx->opt = *opt;
+    return RT_OK;
+}
+
+int rt_reserve(rt_ctx *ctx, int width, int height, int n_samples) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (width <= 0 || height <= 0 || n_samples < 1 || (long long)width * height > 0x7FFFFFFFll)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad width/height/sample count");
+    auto reserve_one = [&](rt_ctx *c, int tile_world) -> int {
+        RT_ON_DEVICE(c);
+        Plan pl;
+        pl.count = n_samples;
+        pl.npix = (size_t)width * (size_t)height;
+        const size_t tiles = (size_t)((width + 7) / 8) * (size_t)((height + 7) / 8);
+        pl.items_per_sample = (tiles + (size_t)tile_world - 1) / (size_t)tile_world * 64;
+        const int S = chunk_samples(pl, kMaxItems);
+        const size_t need_colors = (size_t)S * pl.npix, need_q4 = queue_records((size_t)S * pl.items_per_sample) * 6;
+        const int chunks = (n_samples + S - 1) / S;
+        for (int p = 0; p < (chunks > 1 || c->pipelining ? 2 : 1); p++) {
+            const int rc = ensure_workspace(c, c->pipes[p], need_colors, need_q4);
+            if (rc != RT_OK)
+                return rc;
+        }
+        return ensure_image(c, width, height);
+    };
+    if (ctx->kids.empty())
+        return reserve_one(ctx, ctx->opt.tile_world);
+    const int n = (int)ctx->kids.size();
+    for (rt_ctx *k : ctx->kids) {
+        std::lock_guard<std::mutex> klock(k->mu);
+        const int rc = reserve_one(k, ctx->opt.multi_split == RT_SPLIT_TILE ? ctx->opt.tile_world * n : ctx->opt.tile_world);
+        if (rc != RT_OK)
+            return fail(ctx, rc, "device " + std::to_string(k->device) + ": " + rt_last_error(k));
+    }
     return RT_OK;
 }
 
@@ -618,12 +1034,14 @@ int rt_reset(rt_ctx *ctx) {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    RT_ON_DEVICE(ctx);
     {
         const int jrc = join_pipes(ctx);
         if (jrc != RT_OK)
             return jrc;
     }
+    for (int &s : ctx->kid_samples)
+        s = 0;
     if (ctx->d_image)
         RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_image, 0, (size_t)ctx->img_w * ctx->img_h * sizeof(float4), ctx->stream));
     return RT_OK;
@@ -637,41 +1055,38 @@ int rt_trace(rt_ctx *ctx, int width, int height, int first_sample, int n_samples
     auto t0 = std::chrono::steady_clock::now();
     if (width <= 0 || height <= 0 || (long long)width * height > 0x7FFFFFFFll)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad width/height");
-    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->has_scene)
+        return fail(ctx, RT_ERR_NO_SCENE, "Scene is not loaded.");
+    RT_ON_DEVICE(ctx);
     const size_t px = (size_t)width * (size_t)height;
     {
         const int jrc = join_pipes(ctx); // the image may still be the target of pipelined calls
         if (jrc != RT_OK)
             return jrc;
     }
-    if (width != ctx->img_w || height != ctx->img_h || !ctx->d_image) {
-        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_image) (void)hipFree(ctx->d_image);
-        if (ctx->d_primary) (void)hipFree(ctx->d_primary);
-        ctx->d_image = nullptr;
-        ctx->d_primary = nullptr;
-        ctx->img_w = ctx->img_h = 0;
-        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_image, px * sizeof(float4)));
-        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_primary, px * sizeof(uint32_t)));
-        ctx->img_w = width;
-        ctx->img_h = height;
-        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_image, 0, px * sizeof(float4), ctx->stream));
-    }
-    if (first_sample == 1)
-        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_image, 0, px * sizeof(float4), ctx->stream));
-    if (out_primary_id)
-        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_primary, 0xFF, px * sizeof(uint32_t), ctx->stream));
-    int rc = launch_trace(ctx, width, height, first_sample, n_samples, ctx->d_image, out_primary_id ? ctx->d_primary : nullptr);
+    int rc = ensure_image(ctx, width, height);
     if (rc != RT_OK)
         return rc;
-    rc = join_pipes(ctx);
+    const bool multi = !ctx->kids.empty();
+    if (multi) {
+        rc = multi_trace(ctx, width, height, first_sample, n_samples, ctx->d_image, out_primary_id ? ctx->d_primary : nullptr,
+                         first_sample == 1 || ctx->opt.multi_split == RT_SPLIT_SAMPLE);
+    } else {
+        if (first_sample == 1)
+            RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_image, 0, px * sizeof(float4), ctx->stream));
+        if (out_primary_id)
+            RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_primary, 0xFF, px * sizeof(uint32_t), ctx->stream));
+        rc = launch_trace(ctx, width, height, first_sample, n_samples, ctx->d_image, out_primary_id ? ctx->d_primary : nullptr);
+        if (rc == RT_OK)
+            rc = join_pipes(ctx);
+    }
     if (rc != RT_OK)
         return rc;
     if (out_rgba_mean)
         RT_HIP_CHECK(ctx, hipMemcpyAsync(out_rgba_mean, ctx->d_image, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     if (out_primary_id)
         RT_HIP_CHECK(ctx, hipMemcpyAsync(out_primary_id, ctx->d_primary, px * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    rc = sync_and_stats(ctx, stats);
+    rc = multi ? multi_sync(ctx, stats) : sync_and_stats(ctx, stats);
     if (rc != RT_OK)
         return rc;
     if (stats)
@@ -684,7 +1099,15 @@ int rt_trace_device(rt_ctx *ctx, int width, int height, int first_sample, int n_
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    RT_ON_DEVICE(ctx);
+    if (!ctx->kids.empty()) {
+        if (!ctx->has_scene)
+            return fail(ctx, RT_ERR_NO_SCENE, "Scene is not loaded.");
+        if (!d_rgba)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null image");
+        return multi_trace(ctx, width, height, first_sample, n_samples, (float4 *)d_rgba, d_primary_id,
+                           ctx->opt.multi_split == RT_SPLIT_SAMPLE);
+    }
     return launch_trace(ctx, width, height, first_sample, n_samples, (float4 *)d_rgba, d_primary_id);
 }
 
@@ -692,7 +1115,7 @@ int rt_set_stream(rt_ctx *ctx, void *hip_stream) {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    RT_ON_DEVICE(ctx);
     {
         const int src = sync_all(ctx);
         if (src != RT_OK)
@@ -709,7 +1132,9 @@ int rt_set_pipelining(rt_ctx *ctx, int on) {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->kids.empty())
+        return on ? fail(ctx, RT_ERR_INVALID_ARGUMENT, "overlapping calls is a feature of a single-device context") : RT_OK;
+    RT_ON_DEVICE(ctx);
     const int jrc = join_pipes(ctx);
     if (jrc != RT_OK)
         return jrc;
@@ -721,7 +1146,7 @@ int rt_join(rt_ctx *ctx) {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    RT_ON_DEVICE(ctx);
     return join_pipes(ctx);
 }
 
@@ -729,8 +1154,8 @@ int rt_sync(rt_ctx *ctx, rt_stats *stats) {
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    RT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    return sync_and_stats(ctx, stats);
+    RT_ON_DEVICE(ctx);
+    return ctx->kids.empty() ? sync_and_stats(ctx, stats) : multi_sync(ctx, stats);
 }
 
 int rt_layout_scene(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt_tri *tris, uint32_t n_tris,

@@ -770,3 +770,31 @@ __global__ void __launch_bounds__(256) k_fold(float4 *image, const float4 *color
     image[pixel] = px;
 }
 
+// Several devices behind one context, tile split: `src` is the frame as device `rank` of `world` rendered it (its own
+// 8x8 tiles k with k % world == rank, anything elsewhere); those tiles are copied into the assembled frame.
+__global__ void __launch_bounds__(256) k_take_tiles(float4 *dst, const float4 *src, uint32_t *dst_prim, const uint32_t *src_prim,
+                                                    uint32_t npix, int W, int tiles_x, int rank, int world) {
+    const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
+    if (pixel >= npix)
+        return;
+    const uint32_t x = pixel % (uint32_t)W, y = pixel / (uint32_t)W;
+    const uint32_t tile = (y >> 3) * (uint32_t)tiles_x + (x >> 3);
+    if ((int)(tile % (uint32_t)world) != rank)
+        return;
+    dst[pixel] = src[pixel];
+    if (dst_prim != nullptr)
+        dst_prim[pixel] = src_prim[pixel];
+}
+
+// Several devices behind one context, sample split: the frame is the sum of the devices' own means weighted by their
+// share of the samples, added in device order (first != 0: this is the first term).
+__global__ void __launch_bounds__(256) k_add_weighted(float4 *dst, const float4 *src, uint32_t npix, float w, int first) {
+    const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
+    if (pixel >= npix)
+        return;
+    const float4 s = src[pixel];
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!first)
+        d = dst[pixel];
+    dst[pixel] = make_float4(d.x + s.x * w, d.y + s.y * w, d.z + s.z * w, d.w + s.w * w);
+}

@@ -1,17 +1,19 @@
-"""Multi-GPU partitioning of one render: one process per GPU (torch.distributed; the "nccl" backend is
-RCCL over xGMI on ROCm), scene replicated on every GPU, no collective inside the trace itself.
+"""Multi-GPU partitioning of one render, one process per GPU (torch.distributed; the "nccl" backend is RCCL over xGMI
+on ROCm), scene replicated on every GPU, no collective inside the trace itself.  (Several GPUs inside ONE process are
+rt_create_multi's job, include/rt_hip.h; the two compose.)
 
-Two partitions of the per-pixel loop, both embarrassingly parallel (the reference already splits image
-rows over 16 threads with no communication, Renderer/TraceMethods.cpp:61-72):
+Two partitions of the per-pixel loop, both embarrassingly parallel (the reference already splits image rows over 16
+threads with no communication, Renderer/TraceMethods.cpp:61-72):
 
-* tile split    -- rank r renders the 8x8 tiles k with k % world == r (rt_options.tile_rank/tile_world);
-                   pixels of other ranks stay zero, so ONE reduce(SUM) to rank 0 assembles the image and
-                   is exact (x + 0 == x).
-* sample split  -- rank r renders its own `spp` samples of every pixel with random streams of sample
-                   indices r*spp+1 .. (r+1)*spp (rt_options.sample_offset); ONE reduce(SUM) of the
-                   per-rank means, divided by world, gives the mean over world*spp samples.  That is
-                   a sum-then-divide, not the reference's sequential running mean, so it agrees with a
-                   single-GPU render to rounding, not bit for bit.
+* tile split    -- rank r renders the 8x8 tiles k with k % world == r (rt_options.tile_rank/tile_world); pixels of
+                   other ranks are zero, so ONE reduce(SUM) to rank 0 assembles the image and is exact (x + 0 == x).
+* sample split  -- rank r renders its own share of the samples of every pixel, with the random streams of its own
+                   sample indices (rt_options.sample_offset); ONE reduce(SUM) of the per-rank means, divided by world,
+                   gives the mean over all samples.  That is a sum-then-divide, not the reference's sequential running
+                   mean, so it agrees with a single-GPU render to rounding, not bit for bit.
+
+A render is `n_steps` trace passes accumulated progressively into the rank's image (the reference's sampleCount
+protocol, Renderer/TracerImpl.cpp:9-12) followed by that one reduce.
 """
 import os
 
@@ -37,9 +39,15 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
-def sample_offset(rank, spp):
-    """RNG sample-index offset of `rank` in a sample split with `spp` samples per rank."""
-    return rank * spp
+def sample_offset(rank, samples_per_rank):
+    """RNG sample-index offset of `rank` when every rank renders `samples_per_rank` samples in all: rank r draws the
+    global sample indices r * samples_per_rank + 1 .. (r + 1) * samples_per_rank."""
+    return rank * samples_per_rank
+
+
+def samples_of_rank(spp, rank, world):
+    """Samples of a pass of `spp` samples per pixel that rank `rank` renders in a sample split."""
+    return spp // world + (1 if rank < spp % world else 0)
 
 
 def tile_owner(x, y, width, world):
@@ -48,32 +56,64 @@ def tile_owner(x, y, width, world):
     return ((y // 8) * tiles_x + (x // 8)) % world
 
 
+def share_options(split, rank, world, samples_per_rank=0):
+    """The rt_options fields that give `rank` its share: tile_rank / tile_world, or sample_offset."""
+    if world <= 1:
+        return {}
+    if split == "tile":
+        return {"tile_rank": rank, "tile_world": world}
+    return {"sample_offset": sample_offset(rank, samples_per_rank)}
+
+
 def _reduce_sum(image, dst):
-    """reduce(SUM) onto rank `dst`.  RCCL reduces device tensors in place over xGMI.  gloo (used only to rehearse
-    the multi-rank path where RCCL cannot run, e.g. several ranks sharing one GPU) is given a host copy: its
-    handling of device tensors proved unreliable here (a second reduce of the same CUDA tensor never returned)."""
+    """reduce(SUM) onto rank `dst`, in place on `dst`.  Over RCCL the other ranks' tensors are left as they were; gloo
+    (CPU tests, rehearsals with several ranks on one GPU) uses them as scratch, so they hold no image afterwards.
+
+    gloo with a DEVICE tensor: the host waits for the GPU first.  On this ROCm / torch build a gloo reduce of a device
+    tensor that is entered while kernels are still in flight never returns from the second such call on, when two ranks
+    share one GPU -- with plain torch kernels and no tracer in the process just as with the tracer
+    (tools/gloo_probe.py, modes busy / many against many_sync).  RCCL orders itself behind the current stream and needs
+    no host wait."""
     if image.is_cuda and dist.get_backend() == "gloo":
-        host = image.cpu()
-        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
-        image.copy_(host)
-    else:
-        dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize(image.device)
+    dist.reduce(image, dst=dst, op=dist.ReduceOp.SUM)
 
 
 def combine_tile_split(image, dst=0):
-    """image: this rank's (H, W, 4) float32 tensor, zero outside its tiles.  After the call rank `dst`
-    holds the assembled image."""
+    """image: this rank's (H, W, 4) float32 tensor, ZERO outside its tiles.  After the call rank `dst` holds the
+    assembled image."""
     if dist.is_initialized() and dist.get_world_size() > 1:
         _reduce_sum(image, dst)
     return image
 
 
-def combine_sample_split(image, dst=0):
-    """image: this rank's mean over its own samples.  After the call rank `dst` holds the mean over all
-    ranks' samples."""
+def combine_sample_split(image, dst=0, weight=None):
+    """image: this rank's mean over its own samples.  After the call rank `dst` holds the mean over all ranks'
+    samples.  weight = this rank's share of the samples (None: equal shares, 1 / world)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
         world = dist.get_world_size()
+        if weight is not None:
+            image *= weight
         _reduce_sum(image, dst)
-        if dist.get_rank() == dst:
+        if weight is None and dist.get_rank() == dst:
             image /= world
+    return image
+
+
+def render(trace_pass, join, image, n_steps, split, world):
+    """One render on this rank: `n_steps` passes accumulated into `image`, then the one reduce.
+
+    trace_pass(i): enqueue pass i (samples of step i) into `image` as a running mean, first pass restarting it;
+    join(): order the image after everything enqueued (a stream-level wait is enough).
+    In a tile split a pass writes this rank's tiles only, and on rank `dst` the previous render's reduce left the other
+    ranks' pixels in `image`: the image is cleared first, so that "zero outside its tiles" holds for every render."""
+    if split == "tile" and world > 1:
+        image.zero_()
+    for i in range(n_steps):
+        trace_pass(i)
+    join()
+    if split == "tile":
+        combine_tile_split(image, dst=0)
+    else:
+        combine_sample_split(image, dst=0)
     return image

@@ -8,6 +8,7 @@ from . import _native as N
 EST_SD_LOOP, EST_OLD_RECURSIVE = 0, 1
 TRAV_AUTO, TRAV_LANE, TRAV_WAVE, TRAV_NESTED, TRAV_FAST, TRAV_FAST_REPLAY, TRAV_REFERENCE, TRAV_FAST_REFILL, TRAV_BRUTE, TRAV_FAST_QUEUED, TRAV_FAST_INLINE, TRAV_FAST_SLICED = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 MISS = 0xFFFFFFFF
+SPLIT_TILE, SPLIT_SAMPLE = 0, 1
 
 _STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_HIP", -4: "RT_ERR_NO_SCENE",
            -5: "RT_ERR_BAD_SCENE", -6: "RT_ERR_OUT_OF_MEMORY"}
@@ -59,9 +60,14 @@ class Stats:
 class Tracer:
     """One device context (rt_ctx)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """device: one HIP device; devices: a list of HIP devices behind one context (rt_create_multi)."""
         self._ctx = C.c_void_p()
-        rc = N.hip().rt_create(C.byref(self._ctx), device)
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*devices)
+            rc = N.hip().rt_create_multi(C.byref(self._ctx), ids, len(devices))
+        else:
+            rc = N.hip().rt_create(C.byref(self._ctx), device)
         if rc != 0:
             self._ctx = None
             raise TracerError(rc, "rt_create: no usable HIP device (the tracer has no CPU fallback)")
@@ -93,9 +99,9 @@ class Tracer:
         self._check(N.hip().rt_set_camera(self._ctx, C.byref(c)))
 
     def set_options(self, bounce_limit=4, estimator=EST_SD_LOOP, seed=1, jitter=0.001, tile_rank=0, tile_world=1,
-                    collect_stats=False, sample_offset=0, traversal=0):
+                    collect_stats=False, sample_offset=0, traversal=0, multi_split=0):
         o = N.OptionsC(bounce_limit, estimator, seed, jitter, tile_rank, tile_world, 1 if collect_stats else 0,
-                       sample_offset, traversal)
+                       sample_offset, traversal, multi_split)
         self._check(N.hip().rt_set_options(self._ctx, C.byref(o)))
 
     def reset(self):
@@ -111,9 +117,33 @@ class Tracer:
                                      C.byref(st)))
         return img, prim, Stats(st)
 
+    def trace_host(self, width, height, first_sample, n_samples, host_rgba_ptr):
+        """rt_trace into caller-owned host memory (e.g. page-locked, alloc_host); returns the call's Stats."""
+        st = N.StatsC()
+        self._check(N.hip().rt_trace(self._ctx, width, height, first_sample, n_samples,
+                                     C.cast(host_rgba_ptr, C.POINTER(C.c_float)), None, C.byref(st)))
+        return Stats(st)
+
+    @staticmethod
+    def alloc_host(n_bytes):
+        p = N.hip().rt_alloc_host(n_bytes)
+        if not p:
+            raise MemoryError("rt_alloc_host failed")
+        return p
+
+    @staticmethod
+    def free_host(ptr):
+        N.hip().rt_free_host(ptr)
+
     def trace_device(self, width, height, first_sample, n_samples, d_rgba_ptr, d_primary_ptr=None):
         self._check(N.hip().rt_trace_device(self._ctx, width, height, first_sample, n_samples, d_rgba_ptr,
                                             d_primary_ptr))
+
+    def reserve(self, width, height, n_samples):
+        self._check(N.hip().rt_reserve(self._ctx, width, height, n_samples))
+
+    def device_count(self):
+        return N.hip().rt_device_count(self._ctx)
 
     def set_stream(self, stream_ptr):
         self._check(N.hip().rt_set_stream(self._ctx, stream_ptr))

@@ -19,6 +19,8 @@ CYLINDER = os.path.join(MODELS, "SphereSingle.obj")  # a 32-segment cylinder des
 DEFAULT_CAMERA = Camera(1.0, (0.0, 0.0, 1.0), 2.0, 16.0 / 9.0, (0.0, 0.0, 0.0))
 DRAGON_2426_CAMERA = Camera(1.0, (0.0, 0.10, 0.35), 2.0, 16.0 / 9.0, (-0.006, 0.073, -0.014))
 DRAGON_18520_CAMERA = Camera(1.0, (0.0, 0.10, -0.55), 2.0, 16.0 / 9.0, (-0.006, 0.072, -0.915))
+# configuration 4: the 18 520-triangle dragon with the full-resolution stand-in 0.22 to its right, both in frame
+DRAGON_PAIR_CAMERA = Camera(1.0, (0.105, 0.13, -0.52), 2.0, 16.0 / 9.0, (0.105, 0.06, -0.915))
 RTIOW_CAMERA = Camera(0.5625 / np.tan(np.radians(10.0)), (13.0, 2.0, 3.0), 2.0, 16.0 / 9.0, (0.0, 0.0, 0.0))
 
 
@@ -99,12 +101,80 @@ def dragon_grid_tris(tris24, k, spacing=0.25):
 
 class Workload:
     def __init__(self, name, scene, camera, estimator, width, height, spp, bounce_limit, seed=1, jitter=0.001,
-                 obj_path=None, field_k=0):
+                 models=None, spheres=None, bench_spp=0, description=""):
         self.name, self.scene, self.camera, self.estimator = name, scene, camera, estimator
         self.width, self.height, self.spp, self.bounce_limit = width, height, spp, bounce_limit
         self.seed, self.jitter = seed, jitter
-        # how a checker rebuilds the same scene: the OBJ file, and the side of the grid of copies (0 = the file as is)
-        self.obj_path, self.field_k = obj_path, field_k
+        # samples per pixel of one bench.py step (a step should last tens of milliseconds); default: the configuration's spp
+        self.bench_spp = bench_spp or spp
+        self.description = description
+        # how a checker rebuilds the same scene elsewhere: the triangle soups (n, 24) of the flat scene's models in order, each
+        # one mesh, or the sphere list of the pointer scene
+        self.models, self.spheres = models, spheres
+
+    def scene_bytes(self):
+        """Fast-tree records + triangle positions as uploaded (32 B per node of a full binary tree over the primitives,
+        48 B per triangle): what the walk touches."""
+        prims = len(self.scene.tris()) + len(self.scene.spheres())
+        return 32 * max(2 * prims - 1, 1) + 48 * len(self.scene.tris())
+
+
+def subdivide(tris24, levels=2, centroid_split=True):
+    """Refines a triangle soup (n, 24): `levels` times every triangle is split in four at its edge midpoints, then
+    (centroid_split) in three at its centroid.  Positions and uvs are interpolated linearly in fp32, normals are
+    interpolated and re-normalised; the surface stays the same set of points, covered by 4**levels * 3 times as many
+    triangles."""
+    t = np.ascontiguousarray(tris24, dtype=np.float32).reshape(-1, 3, 8)
+
+    def mid(a, b):
+        m = (a + b) * np.float32(0.5)
+        n = m[:, 3:6]
+        ln = np.sqrt((n * n).sum(axis=1, keepdims=True))
+        m[:, 3:6] = np.where(ln > 0, n / np.maximum(ln, np.float32(1e-30)), a[:, 3:6])
+        return m.astype(np.float32)
+
+    for _ in range(levels):
+        a, b, c = t[:, 0], t[:, 1], t[:, 2]
+        ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+        t = np.stack([np.stack([a, ab, ca], 1), np.stack([ab, b, bc], 1), np.stack([ca, bc, c], 1),
+                      np.stack([ab, bc, ca], 1)], 1).reshape(-1, 3, 8)
+    if centroid_split:
+        a, b, c = t[:, 0], t[:, 1], t[:, 2]
+        g = ((a + b + c) * np.float32(1.0 / 3.0)).astype(np.float32)
+        n = g[:, 3:6]
+        ln = np.sqrt((n * n).sum(axis=1, keepdims=True))
+        g[:, 3:6] = np.where(ln > 0, n / np.maximum(ln, np.float32(1e-30)), a[:, 3:6])
+        t = np.stack([np.stack([a, b, g], 1), np.stack([b, c, g], 1), np.stack([c, a, g], 1)], 1).reshape(-1, 3, 8)
+    return np.ascontiguousarray(t.reshape(-1, 24), dtype=np.float32)
+
+
+def ground_quad(y=0.0, x0=-1.0, x1=1.3, z0=-2.2, z1=0.4):
+    """Two triangles in the plane y = const, normal +y."""
+    def v(x, z):
+        return [x, y, z, 0.0, 1.0, 0.0, 0.0, 0.0]
+    return np.array([v(x0, z0) + v(x0, z1) + v(x1, z1), v(x0, z0) + v(x1, z1) + v(x1, z0)], dtype=np.float32)
+
+
+FULL_DRAGON_SUBSTITUTE = ("substitute for the reference's missing TheStanfordDragon.obj (871 414 triangles): the 18 520-triangle "
+                          "mesh with every triangle split in four twice and in three once (888 960 triangles), moved 0.22 in x")
+
+
+def dragon_pair_models():
+    """Configuration 4's scene as three models: the 18 520-triangle dragon, a stand-in for the full-resolution dragon
+    beside it, and a ground quad under both (the dragon's lowest vertex is at y = 0.0001)."""
+    base = _load_obj_tris(DRAGON_18520)
+    full = subdivide(base, 2, True)
+    full = full.reshape(-1, 3, 8).copy()
+    full[:, :, 0] += np.float32(0.22)
+    return [base, np.ascontiguousarray(full.reshape(-1, 24)), ground_quad()]
+
+
+def sd_workload(name, models, camera, width, height, spp, **kw):
+    sc = SdScene()
+    for m in models:
+        sc.add_model(m)
+    sc.finalize()
+    return Workload(name, sc, camera, EST_SD_LOOP, width, height, spp, 8, models=models, **kw)
 
 
 def field_camera(k, spacing=0.25):
@@ -126,40 +196,49 @@ def _load_obj_tris(path):
     return out.reshape(-1, 24)
 
 
-def dragon_field(name, k, width, height, spp):
+def dragon_field(name, k, width, height, spp, **kw):
     """k x k copies of the 18520-triangle dragon flattened into one triangle list (k = 8: 1.19 M triangles,
     k = 23: 9.8 M), one flat-array scene under the reference's median-split BVH."""
     tris = dragon_grid_tris(_load_obj_tris(DRAGON_18520), k)
-    sc = SdScene().add_model(tris).finalize()
-    return Workload(name, sc, field_camera(k), EST_SD_LOOP, width, height, spp, 8, obj_path=DRAGON_18520, field_k=k)
+    return sd_workload(name, [tris], field_camera(k), width, height, spp,
+                       description=f"{k} x {k} translated copies of TheStanfordDragon18520.obj flattened into one triangle list", **kw)
 
 
 def make_workload(name):
     """Workloads named after the configurations they realise."""
     if name == "dragon18520_1080p":  # the headline: 18520-triangle Stanford Dragon, 1080p
-        sc = SdScene().load_obj(DRAGON_18520).finalize()
-        return Workload(name, sc, DRAGON_18520_CAMERA, EST_SD_LOOP, 1920, 1080, 16, 8, obj_path=DRAGON_18520)
+        return sd_workload(name, [_load_obj_tris(DRAGON_18520)], DRAGON_18520_CAMERA, 1920, 1080, 16, bench_spp=512,
+                           description="TheStanfordDragon18520.obj alone (no ground: about 92 % of the camera rays leave to the sky)")
     if name == "dragon2426_1080p":
-        sc = SdScene().load_obj(DRAGON_2426).finalize()
-        return Workload(name, sc, DRAGON_2426_CAMERA, EST_SD_LOOP, 1920, 1080, 16, 8, obj_path=DRAGON_2426)
-    if name == "dragon18520_4k":
-        sc = SdScene().load_obj(DRAGON_18520).finalize()
-        return Workload(name, sc, DRAGON_18520_CAMERA, EST_SD_LOOP, 3840, 2160, 256, 8, obj_path=DRAGON_18520)
+        return sd_workload(name, [_load_obj_tris(DRAGON_2426)], DRAGON_2426_CAMERA, 1920, 1080, 16, bench_spp=512,
+                           description="TheStanfordDragon2426.obj alone")
+    if name in ("dragon18520_4k", "dragon18520_full_ground_1080p"):
+        # configuration 4 as stated: Dragon18520 + the full dragon on a ground quad, 4K, 256 spp
+        w, h = (3840, 2160) if name.endswith("4k") else (1920, 1080)
+        return sd_workload(name, dragon_pair_models(), DRAGON_PAIR_CAMERA, w, h, 256 if name.endswith("4k") else 16,
+                           bench_spp=256 if name.endswith("4k") else 64,
+                           description="TheStanfordDragon18520.obj + " + FULL_DRAGON_SUBSTITUTE + ", on a ground quad; every ray hits or bounces")
+    if name == "dragon18520_bare_4k":
+        return sd_workload(name, [_load_obj_tris(DRAGON_18520)], DRAGON_18520_CAMERA, 3840, 2160, 256,
+                           description="TheStanfordDragon18520.obj alone at 4K")
     if name == "dragon_field_k8_1080p":   # 1.19 M triangles
-        return dragon_field(name, 8, 1920, 1080, 16)
+        return dragon_field(name, 8, 1920, 1080, 16, bench_spp=64)
     if name == "dragon_field_k8_4k":
         return dragon_field(name, 8, 3840, 2160, 1024)
     if name == "dragon_field_k23_4k":     # 9.8 M triangles: node and triangle records no longer fit the L2
         return dragon_field(name, 23, 3840, 2160, 1024)
     if name == "dragon_field_k23_1080p":
-        return dragon_field(name, 23, 1920, 1080, 16)
+        return dragon_field(name, 23, 1920, 1080, 16, bench_spp=64)
     if name == "rtiow_1080p":
-        sc = build_old_scene(rtiow_spheres()).build()
-        return Workload(name, sc, RTIOW_CAMERA, EST_OLD_RECURSIVE, 1920, 1080, 64, 8, seed=42)
+        sph = rtiow_spheres()
+        sc = build_old_scene(sph).build()
+        return Workload(name, sc, RTIOW_CAMERA, EST_OLD_RECURSIVE, 1920, 1080, 64, 8, seed=42, spheres=sph, bench_spp=128,
+                        description="'Ray Tracing in One Weekend' final scene, 485 spheres, Lambertian / metal / dielectric")
     if name == "plumbing_400x225":
-        sc = build_old_scene(small_sphere_scene())
+        sph = small_sphere_scene()
+        sc = build_old_scene(sph)
         sc.add_obj(CYLINDER, MAT_LAMBERTIAN, (0.8, 0.3, 0.3, 1.0), 0.0)  # material of ModelLoader.hpp:62
         sc.build()
         return Workload(name, sc, Camera(3.19, (13.0, 2.0, 3.0), 2.0, 16.0 / 9.0, (0.0, 0.5, 0.0)), EST_OLD_RECURSIVE,
-                        400, 225, 8, 8)
+                        400, 225, 8, 8, spheres=sph, description="five spheres + SphereSingle.obj (a cylinder)")
     raise KeyError(name)

@@ -28,6 +28,17 @@ def oracle_sd_scene(obj_paths):
     return s
 
 
+def oracle_workload_scene(wl):
+    """The scene of a raytracing_amd.workloads.Workload rebuilt for the oracle."""
+    if wl.estimator == R.EST_SD_LOOP:
+        s = O.SdScene()
+        for tris in wl.models:
+            s.add_model(tris, [len(tris)])
+        s.finalize()
+        return s
+    return oracle_old_scene(wl.spheres)
+
+
 def product_sd_scene(obj_paths):
     s = R.SdScene()
     for p in obj_paths:

@@ -1,7 +1,8 @@
-"""The N > 1 path on CPU: two processes over gloo run the two partitions of raytracing_amd.parallel.
-With no GPU in the process the oracle stands in for the tracer as the per-rank renderer (it takes the
-same tile_rank / tile_world / sample_offset options); what is under test is the partition arithmetic
-and the collective that combines the ranks' images."""
+"""The N > 1 path on CPU: two processes over gloo run raytracing_amd.parallel.render -- the function bench.py runs per
+rank -- for both partitions, twice in a row.  With no GPU in the process the oracle stands in for the tracer as the
+per-rank renderer (it takes the same tile_rank / tile_world / sample_offset options and continues a running mean the
+same way); what is under test is the partition arithmetic, the progressive accumulation across passes and the
+collective that combines the ranks' images, including the state the first render leaves behind for the second."""
 import os
 import sys
 
@@ -13,7 +14,7 @@ import torch.multiprocessing as mp
 
 from helpers import O, ROOT, WL, bits, oracle_camera, oracle_sd_scene
 
-W, H, SPP = 100, 60, 3
+W, H, SPP, STEPS = 100, 60, 2, 2
 
 
 def _worker(rank, world, port, out_dir):
@@ -26,22 +27,24 @@ def _worker(rank, world, port, out_dir):
     assert (r, w) == (rank, world)
     sc = oracle_sd_scene([WL.CYLINDER])
     cam = oracle_camera(WL.DEFAULT_CAMERA)
-    # tile split
-    opt = O.make_options(bounce_limit=4, seed=9, threads=2, tile_rank=r, tile_world=w)
-    img, _, _ = sc.render(cam, opt, W, H, 1, SPP)
-    owner = np.fromfunction(lambda y, x: P.tile_owner(x.astype(int), y.astype(int), W, w), (H, W))
-    assert not img[owner != r].any()
-    t = torch.from_numpy(img)
-    P.combine_tile_split(t, dst=0)
-    if r == 0:
-        np.save(os.path.join(out_dir, "tile.npy"), t.numpy())
-    # sample split
-    opt = O.make_options(bounce_limit=4, seed=9, threads=2, sample_offset=P.sample_offset(r, SPP))
-    img, _, _ = sc.render(cam, opt, W, H, 1, SPP)
-    t = torch.from_numpy(img)
-    P.combine_sample_split(t, dst=0)
-    if r == 0:
-        np.save(os.path.join(out_dir, "sample.npy"), t.numpy())
+    for split in ("tile", "sample"):
+        per_rank = P.samples_of_rank(SPP, r, w)
+        share = P.share_options(split, r, w, samples_per_rank=STEPS * per_rank)
+        opt = O.make_options(bounce_limit=4, seed=9, threads=2, **share)
+        t = torch.zeros((H, W, 4), dtype=torch.float32)
+        n = SPP if split == "tile" else per_rank
+
+        def trace_pass(i):
+            sc.render(cam, opt, W, H, 1 + i * n, n, image=t.numpy())
+
+        for attempt in range(2):   # the second render starts from what the first one's reduce left in `t`
+            P.render(trace_pass, lambda: None, t, STEPS, split, w)
+            if r == 0:
+                np.save(os.path.join(out_dir, f"{split}{attempt}.npy"), t.numpy())
+        if split == "tile":
+            own, _, _ = sc.render(cam, opt, W, H, 1, 1)
+            owner = np.fromfunction(lambda y, x: P.tile_owner(x.astype(int), y.astype(int), W, w), (H, W))
+            assert not own[owner != r].any() and own[owner == r].any()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,7 +55,8 @@ def test_two_rank_partitions_over_gloo(tmp_path):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     sc = oracle_sd_scene([WL.CYLINDER])
     cam = oracle_camera(WL.DEFAULT_CAMERA)
-    full, _, _ = sc.render(cam, O.make_options(bounce_limit=4, seed=9), W, H, 1, SPP)
-    assert np.array_equal(bits(np.load(tmp_path / "tile.npy")), bits(full))          # exact
-    full2, _, _ = sc.render(cam, O.make_options(bounce_limit=4, seed=9), W, H, 1, world * SPP)
-    assert np.allclose(np.load(tmp_path / "sample.npy"), full2, rtol=1e-5, atol=1e-6)  # sum-then-divide vs running mean
+    full, _, _ = sc.render(cam, O.make_options(bounce_limit=4, seed=9), W, H, 1, STEPS * SPP)
+    for attempt in range(2):
+        assert np.array_equal(bits(np.load(tmp_path / f"tile{attempt}.npy")), bits(full))          # exact, both times
+        # sum-then-divide of two running means over disjoint halves of the same sample indices vs one running mean
+        assert np.allclose(np.load(tmp_path / f"sample{attempt}.npy"), full, rtol=1e-5, atol=1e-6)

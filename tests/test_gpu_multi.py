@@ -1,0 +1,79 @@
+"""Several devices behind one context (rt_create_multi), through the C ABI.  The test box has one GPU, so the device list
+names it two or three times: the host threads, the per-device shares, the peer copies and the assembly run as they would
+over distinct GPUs."""
+import numpy as np
+import pytest
+
+from helpers import R, WL, bits, product_sd_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return product_sd_scene([WL.DRAGON_2426])
+
+
+@pytest.mark.parametrize("n_dev", [2, 3])
+def test_tile_split_is_bit_identical_to_one_device(scene, n_dev):
+    one = R.Tracer(0)
+    one.upload(scene)
+    one.set_camera(WL.DRAGON_2426_CAMERA)
+    one.set_options(bounce_limit=6, seed=4, collect_stats=True)
+    multi = R.Tracer(devices=[0] * n_dev)
+    assert multi.device_count() == n_dev
+    multi.upload(scene)
+    multi.set_camera(WL.DRAGON_2426_CAMERA)
+    multi.set_options(bounce_limit=6, seed=4, collect_stats=True, multi_split=R.SPLIT_TILE)
+    for (w, h) in ((250, 141), (640, 360)):
+        a, ap, ast = one.trace(w, h, 1, 3, want_primary=True)
+        b, bp, bst = multi.trace(w, h, 1, 3, want_primary=True)
+        assert np.array_equal(ap, bp) and np.array_equal(bits(a), bits(b))
+        assert (ast.rays, ast.box_tests, ast.tri_tests, ast.tri_hits) == (bst.rays, bst.box_tests, bst.tri_tests, bst.tri_hits)
+        a, _, _ = one.trace(w, h, 4, 2)      # the progressive protocol goes on across calls
+        b, _, _ = multi.trace(w, h, 4, 2)
+        assert np.array_equal(bits(a), bits(b))
+    one.close()
+    multi.close()
+
+
+def test_sample_split_matches_one_device_to_rounding(scene):
+    one = R.Tracer(0)
+    one.upload(scene)
+    one.set_camera(WL.DRAGON_2426_CAMERA)
+    one.set_options(bounce_limit=6, seed=4)
+    multi = R.Tracer(devices=[0, 0, 0])
+    multi.upload(scene)
+    multi.set_camera(WL.DRAGON_2426_CAMERA)
+    multi.set_options(bounce_limit=6, seed=4, multi_split=R.SPLIT_SAMPLE)
+    a, ap, ast = one.trace(320, 180, 1, 8, want_primary=True)
+    b, bp, bst = multi.trace(320, 180, 1, 8, want_primary=True)   # shares 3, 3, 2
+    assert ast.rays == bst.rays and np.array_equal(ap, bp)
+    # a weighted sum of three running means against one running mean: rounding only
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
+    a, _, ast = one.trace(320, 180, 9, 4)
+    b, _, bst = multi.trace(320, 180, 9, 4)                      # continues: shares 2, 1, 1
+    assert ast.rays == bst.rays
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
+    one.close()
+    multi.close()
+
+
+def test_multi_device_output_on_the_device_and_refusals(scene):
+    import torch
+    multi = R.Tracer(devices=[0, 0])
+    multi.upload(scene)
+    multi.set_camera(WL.DRAGON_2426_CAMERA)
+    multi.set_options(bounce_limit=4, seed=9)
+    multi.reserve(256, 144, 2)
+    img = torch.zeros((144, 256, 4), dtype=torch.float32, device="cuda:0")
+    multi.trace_device(256, 144, 1, 2, img.data_ptr())
+    multi.sync()
+    ref, _, _ = multi.trace(256, 144, 1, 2)
+    assert np.array_equal(bits(img.cpu().numpy()), bits(ref))
+    with pytest.raises(R.TracerError):
+        multi.set_pipelining(True)
+    multi.close()
+    with pytest.raises(R.TracerError) as e:
+        R.Tracer(devices=[0, 99])
+    assert e.value.code == -2

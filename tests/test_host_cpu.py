@@ -100,15 +100,20 @@ def test_old_scene_builder_matches_oracle_tree():
 
 def test_c_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char \*)\s*\*?(rt_[a-z_]+)\(", hdr, re.M))
+    declared = set(re.findall(r"^(?:int|void|uint64_t|const char \*)\s*\*?(rt_[a-z_]+)\(", hdr, re.M))
     assert declared == set(N.HIP_SYMBOLS), declared ^ set(N.HIP_SYMBOLS)
     lib = N.hip()
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.rt_version().decode().endswith("gfx950")
+    import torch
+    if not torch.cuda.is_available():   # no GPU in a CPU run: creation is refused, never faked
+        ctx = C.c_void_p()
+        ids = (C.c_int * 2)(0, 1)
+        assert lib.rt_create_multi(C.byref(ctx), ids, 2) == -2 and not ctx.value
     assert C.sizeof(N.Node) == 36 and C.sizeof(N.Tri) == 100          # == sizeof(sd::Node), sizeof(sd::Triangle)
     assert N.Node.flags.offset == 32 and N.Tri.mat.offset == 96
-    assert C.sizeof(N.CameraC) == 40 and C.sizeof(N.OptionsC) == 36 and C.sizeof(N.StatsC) == 64
+    assert C.sizeof(N.CameraC) == 40 and C.sizeof(N.OptionsC) == 40 and C.sizeof(N.StatsC) == 64
 
 
 def test_kernels_are_compiled_for_gfx950(tmp_path):
