@@ -183,7 +183,7 @@ int rt_create(rt_ctx **out, int device);
  * together on device_ids[0] (peer copies over xGMI), where d_rgba of rt_trace_device must live.  rt_options.tile_rank /
  * tile_world / sample_offset keep their meaning for the context as a whole, so processes and devices can be combined.
  * rt_trace_device returns when the devices have finished their shares (the assembly is enqueued on the context's
- * stream); rt_set_pipelining(1) is refused.  n_devices == 1 is rt_create. */
+ * stream); rt_set_pipelining(1) and rt_trace_device_noalloc are refused.  n_devices == 1 is rt_create. */
 int rt_create_multi(rt_ctx **out, const int *device_ids, int n_devices);
 int rt_device_count(rt_ctx *ctx); /* devices behind the context */
 void rt_destroy(rt_ctx *ctx);
@@ -231,6 +231,19 @@ int rt_trace(rt_ctx *ctx, int width, int height, int first_sample, int n_samples
  * NULL).  Enqueued on the context's stream; nothing is copied to the host. */
 int rt_trace_device(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *d_rgba,
                     uint32_t *d_primary_id);
+/* rt_trace_device for callers that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  It has no counterpart in the reference.  Same work and same results as rt_trace_device, but the
+ * call makes no allocation of any kind (no hipMalloc / hipFree, no event or stream creation): every launch goes to the
+ * context's stream, one chunk of samples after the other, in a workspace that is part of the library's code object --
+ * one static array of about 107 MB per GPU the library runs on, held until the process ends.  Limit: this context's
+ * share of the frame, counted in whole 8x8 tiles, must not exceed rt_noalloc_max_pixels() = 262 144 pixels (the
+ * reference's 640x360 window is 230 400); larger frames are refused with RT_ERR_INVALID_ARGUMENT.  Every context on a
+ * GPU shares that GPU's workspace: calls that overlap on one GPU (two contexts, or one context whose stream was changed
+ * while work was pending) race.  Kernel times are not recorded for these calls (rt_stats.launches does not count them);
+ * the ray counters are. */
+int rt_trace_device_noalloc(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *d_rgba,
+                            uint32_t *d_primary_id);
+uint64_t rt_noalloc_max_pixels(void);
 /* Lets consecutive rt_trace_device calls overlap (off by default).  Internally the tracer works in chunks on two
  * streams of its own so that the latency-bound end of one chunk overlaps the start of the next; by default every call
  * ends by making the context's stream wait for its chunks, which keeps the ordering promise above but lets nothing

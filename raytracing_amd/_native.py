@@ -60,7 +60,7 @@ assert C.sizeof(Node) == 36 and C.sizeof(Tri) == 100 and C.sizeof(Sphere) == 24 
 HIP_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_set_options",
                "rt_reset", "rt_trace", "rt_trace_device", "rt_set_stream", "rt_sync", "rt_version", "rt_layout_scene",
                "rt_layout_free", "rt_set_pipelining", "rt_join", "rt_alloc_host", "rt_free_host", "rt_create_multi",
-               "rt_device_count", "rt_reserve"]
+               "rt_device_count", "rt_reserve", "rt_trace_device_noalloc", "rt_noalloc_max_pixels"]
 
 _hip = None
 _host = None
@@ -78,6 +78,8 @@ def hip():
         L.rt_create_multi.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
         L.rt_device_count.argtypes = [vp]
         L.rt_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+        L.rt_trace_device_noalloc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+        L.rt_noalloc_max_pixels.restype = C.c_uint64
         L.rt_destroy.argtypes = [vp]
         L.rt_destroy.restype = None
         L.rt_last_error.argtypes = [vp]

@@ -58,8 +58,20 @@ namespace {
 
 // ===================================================================== host side of the C ABI
 
+// Built-in workspace of rt_trace_device_noalloc: one array per GPU, part of the code object, so that entry point never
+// has to ask the runtime for memory.  It holds what a chunk of the wavefront tracer needs for at most kScratchMaxItems
+// pixel samples: the per-level sub-queue counters, the per-sample colours and the two path queues (sized for the
+// largest record, six float4).  In host code the array's name is only a handle for hipGetSymbolAddress; the address
+// each device holds it at is looked up once per device (scratch_of) and that pointer is what kernels and memsets get.
+constexpr size_t kScratchMaxItems = 256u << 10; // pixel samples per chunk = pixels of the largest frame, in whole 8x8 tiles
+constexpr size_t round256(size_t v) { return (v + 255u) & ~(size_t)255u; }
 constexpr size_t kLevelWords = (size_t)(kMaxLevels + 1) * kSubQueues * 32;
 constexpr size_t kQueueSlack = (size_t)kSubQueues * 66 * 64; // see queue_records
+constexpr size_t kScratchLevelsBytes = round256(kLevelWords * sizeof(unsigned int));
+constexpr size_t kScratchColorsBytes = round256(kScratchMaxItems * sizeof(float4));
+constexpr size_t kScratchQueueBytes = round256((kScratchMaxItems + kQueueSlack) * 6 * sizeof(float4));
+constexpr size_t kScratchBytes = kScratchLevelsBytes + kScratchColorsBytes + 2 * kScratchQueueBytes; // about 107 MB
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 // What one chunk of the wavefront tracer works in.
 struct Workspace {
@@ -115,6 +127,7 @@ struct rt_ctx {
     hipEvent_t last_fold = nullptr; // `done` of the pipe that ran the latest fold
     bool pipelining = false;        // rt_set_pipelining: calls may overlap; rt_join / rt_sync order their results
     bool joined = true;             // the context's stream has been made to wait for both pipes
+    void *scratch_ptr = nullptr;    // this device's copy of `scratch` (rt_trace_device_noalloc)
     // rt_create_multi: this context only coordinates; kids[r] is an ordinary context on device r of the list, and
     // `device` / `stream` / `d_image` belong to the first device of the list, where the frame is put together.
     std::vector<rt_ctx *> kids;
@@ -161,6 +174,24 @@ struct DeviceGuard {
 #define RT_ON_DEVICE(ctx)                                                                                      \
     DeviceGuard device_guard_((ctx)->device);                                                                  \
     RT_HIP_CHECK(ctx, device_guard_.rc)
+
+// Address of `scratch` on each device, looked up once per device with that device current.
+std::mutex g_scratch_mu;
+std::vector<void *> g_scratch_ptr;
+int scratch_of(rt_ctx *ctx, int device, void **out) {
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if ((size_t)device >= g_scratch_ptr.size())
+        g_scratch_ptr.resize((size_t)device + 1, nullptr);
+    if (g_scratch_ptr[device] == nullptr) {
+        void *p = nullptr;
+        RT_HIP_CHECK(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (p == nullptr)
+            return fail(ctx, RT_ERR_HIP, "hipGetSymbolAddress returned no address for the built-in workspace");
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
 
 void free_scene(rt_ctx *c) {
     if (c->d_nodes) (void)hipFree(c->d_nodes);
@@ -542,6 +573,51 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     return RT_OK;
 }
 
+// The same work with no allocation of any kind: every launch goes to the context's stream, one chunk after the other, in
+// the device's built-in workspace; no timing events are taken.
+int launch_trace_noalloc(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim) {
+    Plan pl;
+    {
+        const int prc = make_plan(ctx, W, H, first, count, d_img, d_prim, pl);
+        if (prc != RT_OK)
+            return prc;
+    }
+    if (pl.items_per_sample > kScratchMaxItems)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT,
+                    "rt_trace_device_noalloc: the frame is too large for the built-in workspace (at most " +
+                        std::to_string(kScratchMaxItems) + " pixels, counted in whole 8x8 tiles; this context's share of the frame has " +
+                        std::to_string(pl.items_per_sample) + ")");
+    if (ctx->scratch_ptr == nullptr)
+        return fail(ctx, RT_ERR_HIP, "the built-in workspace has no address on this device");
+    {
+        const int jrc = join_pipes(ctx); // earlier pipelined calls may still be folding into this image
+        if (jrc != RT_OK)
+            return jrc;
+    }
+    ctx->counted = true;
+    if (pl.nested)
+        return launch_nested(ctx, pl, ctx->stream);
+    unsigned char *base = (unsigned char *)ctx->scratch_ptr;
+    Workspace ws;
+    ws.levels = (unsigned int *)base;
+    ws.colors = (float4 *)(base + kScratchLevelsBytes);
+    ws.q[0] = (float4 *)(base + kScratchLevelsBytes + kScratchColorsBytes);
+    ws.q[1] = (float4 *)(base + kScratchLevelsBytes + kScratchColorsBytes + kScratchQueueBytes);
+    ws.colors_cap = kScratchMaxItems;
+    ws.q_cap = (kScratchMaxItems + kQueueSlack) * 6;
+    const int S = chunk_samples(pl, kScratchMaxItems); // S * npix <= S * items <= kScratchMaxItems: the colours fit too
+    for (int done = 0; done < count; done += S) {
+        const int s_now = count - done < S ? count - done : S;
+        KParams P;
+        int rc = launch_chunk(ctx, pl, ws, ctx->stream, done, s_now, P);
+        if (rc == RT_OK)
+            rc = launch_fold(ctx, pl, ws, ctx->stream, P);
+        if (rc != RT_OK)
+            return rc;
+    }
+    return RT_OK;
+}
+
 void add_stats(rt_stats &a, const rt_stats &b) {
     a.rays += b.rays;
     a.box_tests += b.box_tests;
@@ -711,6 +787,7 @@ int create_single(rt_ctx **out, int device) {
         if (hipEventCreateWithFlags(&pp.done, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
         if (hipMalloc((void **)&pp.ws.levels, kLevelWords * sizeof(unsigned int)) != hipSuccess) return bail("hipMalloc");
     }
+    if (scratch_of(ctx, device, &ctx->scratch_ptr) != RT_OK) return bail("hipGetSymbolAddress");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail("hipGetDeviceProperties");
     ctx->num_cus = prop.multiProcessorCount;
@@ -1110,6 +1187,19 @@ int rt_trace_device(rt_ctx *ctx, int width, int height, int first_sample, int n_
     }
     return launch_trace(ctx, width, height, first_sample, n_samples, (float4 *)d_rgba, d_primary_id);
 }
+
+int rt_trace_device_noalloc(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *d_rgba,
+                            uint32_t *d_primary_id) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->kids.empty())
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_trace_device_noalloc works on a single-device context");
+    RT_ON_DEVICE(ctx);
+    return launch_trace_noalloc(ctx, width, height, first_sample, n_samples, (float4 *)d_rgba, d_primary_id);
+}
+
+uint64_t rt_noalloc_max_pixels(void) { return (uint64_t)kScratchMaxItems; }
 
 int rt_set_stream(rt_ctx *ctx, void *hip_stream) {
     if (!ctx)

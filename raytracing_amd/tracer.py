@@ -139,6 +139,10 @@ class Tracer:
         self._check(N.hip().rt_trace_device(self._ctx, width, height, first_sample, n_samples, d_rgba_ptr,
                                             d_primary_ptr))
 
+    def trace_device_noalloc(self, width, height, first_sample, n_samples, d_rgba_ptr, d_primary_ptr=None):
+        self._check(N.hip().rt_trace_device_noalloc(self._ctx, width, height, first_sample, n_samples, d_rgba_ptr,
+                                                    d_primary_ptr))
+
     def reserve(self, width, height, n_samples):
         self._check(N.hip().rt_reserve(self._ctx, width, height, n_samples))
 

@@ -106,6 +106,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.rt_version().decode().endswith("gfx950")
+    assert lib.rt_noalloc_max_pixels() == 256 * 1024
     import torch
     if not torch.cuda.is_available():   # no GPU in a CPU run: creation is refused, never faked
         ctx = C.c_void_p()
