@@ -144,6 +144,13 @@ enum {
  *           the frame is sum_r mean_r * (samples_r / samples) -- equal to one device's running mean to rounding. */
 enum { RT_SPLIT_TILE = 0, RT_SPLIT_SAMPLE = 1 };
 
+/* Where the camera rays of the fast walks are made (results are the same bits either way).
+ *   SEPARATE: a kernel of its own makes them and runs the walk's first slab test (the scene's root box); only rays that
+ *             pass are queued for the path kernels, the others are sky and cost no queue or colour slot.
+ *   FUSED:    the path kernel's first launch makes them and walks them in place.
+ *   AUTO:     SEPARATE when the root box's projection covers less than half of the frame. */
+enum { RT_CAMERA_AUTO = 0, RT_CAMERA_SEPARATE = 1, RT_CAMERA_FUSED = 2 };
+
 typedef struct rt_options {
     int32_t bounce_limit; /* Trace::bounceLimit, CPURayTrace/Trace.hpp:16 */
     int32_t estimator;    /* RT_EST_* */
@@ -156,6 +163,7 @@ typedef struct rt_options {
                                accumulate a mean over n samples of disjoint random streams (sample-range split) */
     int32_t traversal;      /* RT_TRAV_* */
     int32_t multi_split;    /* RT_SPLIT_*: how a context made by rt_create_multi shares a call among its devices */
+    int32_t camera_stage;   /* RT_CAMERA_* */
 } rt_options;
 
 typedef struct rt_stats {
@@ -286,6 +294,12 @@ void rt_layout_free(rt_layout_view *view);
  * bounce buffer.  rt_alloc_host returns NULL on failure; any host pointer works with rt_trace, these are only faster. */
 void *rt_alloc_host(uint64_t bytes);
 void rt_free_host(void *ptr);
+
+/* Self-test hook: the kernels' own fp32 vector helpers (one source for host and device, csrc/rt_device_common.hpp)
+ * evaluated on the host, so that their operation order -- glm's scalar definitions, which every value of the reference
+ * goes through (CPURayTrace/SimplifiedData.cpp:274-293, Include/Camera.hpp:35-46) -- can be pinned without a GPU.
+ * op 0 dot(a, b) -> out3[0]; 1 cross(a, b); 2 normalize(a); 3 mat3(a, b, c) * v.  Unused pointers may be NULL. */
+void rt_vec_op(int op, const float *a, const float *b, const float *c, const float *v, float *out3);
 
 /* Library self-description: "rt_hip <version> gfx950". */
 const char *rt_version(void);

@@ -92,6 +92,7 @@ def lib():
         L.ora_sincos.argtypes = [C.c_float, C.c_int, fp, fp]
         L.ora_camera_dir.argtypes = [C.POINTER(Camera), C.c_float, C.c_float, fp]
         L.ora_cosine_dir.argtypes = [fp, C.c_float, C.c_float, C.c_int, fp]
+        L.ora_vec_op.argtypes = [C.c_int, fp, fp, fp, fp, fp]
         _lib = L
     return _lib
 
@@ -280,6 +281,17 @@ def cosine_dir(normal, u1, u2, trig):
     out = np.zeros(3, dtype=np.float32)
     lib().ora_cosine_dir(np_, u1, u2, trig, out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
+
+
+VEC_DOT, VEC_CROSS, VEC_NORMALIZE, VEC_MAT3_MUL, VEC_MIN, VEC_MAX = 0, 1, 2, 3, 4, 5
+
+
+def vec_op(op, a, b=None, c=None, v=None):
+    """The oracle's own vector helpers (glm's scalar definitions): dot -> float, the others -> float32[3]."""
+    out = np.zeros(3, dtype=np.float32)
+    keep = [_f(x) if x is not None else (None, None) for x in (a, b, c, v)]
+    lib().ora_vec_op(op, keep[0][1], keep[1][1], keep[2][1], keep[3][1], out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[0] if op == VEC_DOT else out
 
 
 def take_leaf_replays():

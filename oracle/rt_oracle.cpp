@@ -1124,6 +1124,22 @@ void ora_camera_dir(const ora_camera *cam, float u, float v, float *out3) {
     V3 d = camera_dir(*cam, u, v);
     out3[0] = d.x; out3[1] = d.y; out3[2] = d.z;
 }
+// The vector helpers themselves, for known-answer tests of their operation order: op 0 dot(a, b) -> out[0]; 1 cross(a, b);
+// 2 normalize(a); 3 mat3(a, b, c) * v; 4 component-wise min(a, b); 5 component-wise max(a, b).
+void ora_vec_op(int op, const float *a, const float *b, const float *c, const float *v, float *out3) {
+    const V3 A{a[0], a[1], a[2]}, B = b ? V3{b[0], b[1], b[2]} : V3{0, 0, 0}, C = c ? V3{c[0], c[1], c[2]} : V3{0, 0, 0},
+             X = v ? V3{v[0], v[1], v[2]} : V3{0, 0, 0};
+    V3 r{0, 0, 0};
+    switch (op) {
+    case 0: r.x = dot(A, B); break;
+    case 1: r = cross(A, B); break;
+    case 2: r = normalize(A); break;
+    case 3: r = mat3_mul(A, B, C, X); break;
+    case 4: r = vmin(A, B); break;
+    default: r = vmax(A, B); break;
+    }
+    out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
 void ora_cosine_dir(const float *n, float u1, float u2, int trig, float *out3) {
     V3 d = cosine_dir(V3{n[0], n[1], n[2]}, u1, u2, trig);
     out3[0] = d.x; out3[1] = d.y; out3[2] = d.z;

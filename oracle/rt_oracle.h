@@ -124,6 +124,9 @@ int ora_box_test(const float *pmin, const float *pmax, const float *origin, cons
 uint32_t ora_rng_u32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t dim);
 void ora_sincos(float theta, int trig, float *s, float *c);
 void ora_camera_dir(const ora_camera *cam, float u, float v, float *out3);
+/* the oracle's own vector helpers (glm's scalar definitions), for known-answer tests of their operation order:
+ * op 0 dot(a, b) -> out3[0]; 1 cross(a, b); 2 normalize(a); 3 mat3(a, b, c) * v; 4 / 5 component-wise min / max(a, b) */
+void ora_vec_op(int op, const float *a, const float *b, const float *c, const float *v, float *out3);
 void ora_cosine_dir(const float *normal, float u1, float u2, int trig, float *out3);
 
 #ifdef __cplusplus

@@ -39,7 +39,8 @@ class CameraC(C.Structure):  # rt_camera
 class OptionsC(C.Structure):  # rt_options
     _fields_ = [("bounce_limit", C.c_int32), ("estimator", C.c_int32), ("seed", C.c_uint32), ("jitter", C.c_float),
                 ("tile_rank", C.c_int32), ("tile_world", C.c_int32), ("collect_stats", C.c_int32),
-                ("sample_offset", C.c_uint32), ("traversal", C.c_int32), ("multi_split", C.c_int32)]
+                ("sample_offset", C.c_uint32), ("traversal", C.c_int32), ("multi_split", C.c_int32),
+                ("camera_stage", C.c_int32)]
 
 
 class StatsC(C.Structure):  # rt_stats
@@ -60,7 +61,7 @@ assert C.sizeof(Node) == 36 and C.sizeof(Tri) == 100 and C.sizeof(Sphere) == 24 
 HIP_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_set_options",
                "rt_reset", "rt_trace", "rt_trace_device", "rt_set_stream", "rt_sync", "rt_version", "rt_layout_scene",
                "rt_layout_free", "rt_set_pipelining", "rt_join", "rt_alloc_host", "rt_free_host", "rt_create_multi",
-               "rt_device_count", "rt_reserve", "rt_trace_device_noalloc", "rt_noalloc_max_pixels"]
+               "rt_device_count", "rt_reserve", "rt_vec_op", "rt_trace_device_noalloc", "rt_noalloc_max_pixels"]
 
 _hip = None
 _host = None
@@ -80,6 +81,8 @@ def hip():
         L.rt_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.rt_trace_device_noalloc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.rt_noalloc_max_pixels.restype = C.c_uint64
+        L.rt_vec_op.argtypes = [C.c_int, fp, fp, fp, fp, fp]
+        L.rt_vec_op.restype = None
         L.rt_destroy.argtypes = [vp]
         L.rt_destroy.restype = None
         L.rt_last_error.argtypes = [vp]

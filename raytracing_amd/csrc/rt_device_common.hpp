@@ -65,6 +65,9 @@ struct KParams {
     const float4 *q_in;         // path records of this level (4 x float4 each)
     float4 *q_out;              // path records of the next level
     float4 *colors;             // colors[sample in chunk][pixel]
+    unsigned long long *deferred; // camera stage: per pixel, bit s set = sample s of the chunk went to the queue (its colour
+                                  // comes through `colors`); clear = it left to the sky at once (k_fold works it out itself)
+    int camera_stage;           // the chunk starts with k_camera; the path kernels run at levels 1 ..
     const unsigned int *sub_in; // levels > 0: record counts of this level's sub-queues (one per 128 bytes)
     unsigned int *sub_cursor;   // levels > 0: batch cursors of this level's sub-queues (one per 128 bytes)
     unsigned int *sub_out;      // append counters of the next level's sub-queues

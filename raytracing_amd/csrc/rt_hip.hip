@@ -34,6 +34,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -70,14 +71,17 @@ constexpr size_t kQueueSlack = (size_t)kSubQueues * 66 * 64; // see queue_record
 constexpr size_t kScratchLevelsBytes = round256(kLevelWords * sizeof(unsigned int));
 constexpr size_t kScratchColorsBytes = round256(kScratchMaxItems * sizeof(float4));
 constexpr size_t kScratchQueueBytes = round256((kScratchMaxItems + kQueueSlack) * 6 * sizeof(float4));
-constexpr size_t kScratchBytes = kScratchLevelsBytes + kScratchColorsBytes + 2 * kScratchQueueBytes; // about 107 MB
+constexpr size_t kScratchDeferredBytes = round256(kScratchMaxItems * sizeof(unsigned long long));
+constexpr size_t kScratchBytes = kScratchLevelsBytes + kScratchColorsBytes + kScratchDeferredBytes + 2 * kScratchQueueBytes; // about 109 MB
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 // What one chunk of the wavefront tracer works in.
 struct Workspace {
     float4 *colors = nullptr, *q[2] = {nullptr, nullptr};
     unsigned int *levels = nullptr;   // per level: 64 sub-queue slots of 32 words (count, batch cursor)
+    unsigned long long *deferred = nullptr; // per pixel: which samples of the chunk the camera stage queued
     size_t colors_cap = 0, q_cap = 0; // capacities in float4
+    size_t deferred_cap = 0;          // pixels
 };
 
 struct rt_ctx {
@@ -96,6 +100,7 @@ struct rt_ctx {
     size_t scene_bytes = 0; // fast-tree records + triangle positions
     bool fast_exact = true; // the uploaded tree's interior boxes contain their children's (see build_layout)
     double expected_visits = 0.0; // sum of node box areas / root box area: nodes a random ray through the root meets
+    float root_box[6] = {0, 0, 0, 0, 0, 0}; // box of the fast tree's root record: pMin.xyz, pMax.xyz
     rt_camera cam;
     bool has_camera = false;
     rt_options opt;
@@ -211,8 +216,10 @@ void free_workspace(Workspace &ws) {
     if (ws.colors) (void)hipFree(ws.colors);
     if (ws.q[0]) (void)hipFree(ws.q[0]);
     if (ws.q[1]) (void)hipFree(ws.q[1]);
+    if (ws.deferred) (void)hipFree(ws.deferred);
     ws.colors = ws.q[0] = ws.q[1] = nullptr;
-    ws.colors_cap = ws.q_cap = 0;
+    ws.deferred = nullptr;
+    ws.colors_cap = ws.q_cap = ws.deferred_cap = 0;
 }
 
 inline float u2f(uint32_t u) {
@@ -268,16 +275,69 @@ int sync_all(rt_ctx *ctx) {
     return RT_OK;
 }
 
+// The tracer's tuning constants; each can be overridden from the environment for measurements (RT_SLICE, RT_TAIL_RAYS,
+// RT_EXTRA_ROUNDS, RT_CHUNK_SAMPLES), read once per process.  Results do not depend on them.
+struct Tuning {
+    uint32_t slice = kSlice, tail_rays = kTailRays;
+    int extra_rounds = kSliceExtraRounds, chunk_samples = kChunkSamples;
+};
+const Tuning &tuning() {
+    static const Tuning t = [] {
+        Tuning v;
+        auto env = [](const char *name, long lo, long hi, long dflt) {
+            const char *e = std::getenv(name);
+            if (!e || !*e)
+                return dflt;
+            const long x = std::strtol(e, nullptr, 10);
+            return x < lo ? lo : x > hi ? hi : x;
+        };
+        v.slice = (uint32_t)env("RT_SLICE", 1, 1 << 20, kSlice);
+        v.tail_rays = (uint32_t)env("RT_TAIL_RAYS", 0, 1 << 30, kTailRays);
+        v.extra_rounds = (int)env("RT_EXTRA_ROUNDS", 0, 32, kSliceExtraRounds);
+        v.chunk_samples = (int)env("RT_CHUNK_SAMPLES", 1, kChunkSamples, kChunkSamples);
+        return v;
+    }();
+    return t;
+}
+
 // Everything about a trace call that does not depend on the chunk: kernel parameters, which kernel, how many launches.
 struct Plan {
     KParams P;
     int variant = 0, walk = 0, levels = 1;
     bool nested = false, sliced = false, queued = false, refill = false;
+    bool camera = false;        // the chunk starts with k_camera, the path kernels run at levels 1 .. levels
     uint32_t full_grid = 1;
     size_t rec4 = 4;            // float4 per queue record
     size_t npix = 0, items_per_sample = 0;
     int W = 0, H = 0, first = 1, count = 0;
 };
+
+// Part of the frame covered by the projection of the scene's root box (the bounding rectangle of its eight corners in
+// the camera's uv coordinates, Camera.hpp:33-47), 1 when a corner lies behind the camera.
+double root_box_coverage(const rt_ctx *ctx) {
+    const rt_camera &c = ctx->cam;
+    const f3 pos = mk3(c.position[0], c.position[1], c.position[2]);
+    const f3 z = normalize3(mk3(c.look_at[0], c.look_at[1], c.look_at[2]) - pos);
+    const f3 x = normalize3(cross3(mk3(0.f, 1.f, 0.f), z));
+    const f3 y = cross3(z, x);
+    double u0 = 1e30, u1 = -1e30, v0 = 1e30, v1 = -1e30;
+    for (int k = 0; k < 8; k++) {
+        const f3 r = mk3(ctx->root_box[(k & 1) ? 3 : 0], ctx->root_box[(k & 2) ? 4 : 1], ctx->root_box[(k & 4) ? 5 : 2]) - pos;
+        const double cz = dot3(r, z);
+        if (!(cz > 1e-6))
+            return 1.0;
+        const double u = (-(double)dot3(r, x) * c.focal_length / cz + c.width / 2) / c.width;
+        const double v = ((double)dot3(r, y) * c.focal_length / cz + c.height / 2) / c.height;
+        if (!(u == u) || !(v == v))
+            return 1.0;
+        u0 = u < u0 ? u : u0;
+        u1 = u > u1 ? u : u1;
+        v0 = v < v0 ? v : v0;
+        v1 = v > v1 ? v : v1;
+    }
+    auto clip = [](double a) { return a < 0.0 ? 0.0 : a > 1.0 ? 1.0 : a; };
+    return (clip(u1) - clip(u0)) * (clip(v1) - clip(v0));
+}
 
 // Queue records a chunk of `items` pixel samples needs: a sub-queue of the next level receives the continuing paths
 // (at most 64) of every 64th batch of level 0, or of every 64th batch of each of this level's 64 sub-queues; no level
@@ -368,12 +428,21 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     pl.items_per_sample = (size_t)P.n_my_tiles * 64;
     pl.levels = old ? o.bounce_limit + 1 : (o.bounce_limit > 1 ? o.bounce_limit : 1);
     if (pl.sliced) { // rounds, not bounce levels: a walk may take several; the last launch finishes whatever is left
-        pl.levels += kSliceExtraRounds;
+        pl.levels += tuning().extra_rounds;
         if (pl.levels > kMaxLevels - 1)
             pl.levels = kMaxLevels - 1;
     }
-    P.slice = kSlice;
-    P.tail_rays = kTailRays;
+    // Camera stage: worth it when most camera rays miss the scene altogether -- judged by the part of the frame the root
+    // box's projection covers -- and possible when the walk is the fast tree's (the stage tests that tree's root record).
+    pl.camera = false;
+    if (pl.walk == WALK_FAST && !(!old && o.bounce_limit <= 0) && o.camera_stage != RT_CAMERA_FUSED)
+        pl.camera = o.camera_stage == RT_CAMERA_SEPARATE || root_box_coverage(ctx) < 0.5;
+    if (pl.camera && pl.levels + 1 > kMaxLevels - 1)
+        pl.camera = false;
+    P.camera_stage = pl.camera ? 1 : 0;
+    P.deferred = nullptr;
+    P.slice = tuning().slice;
+    P.tail_rays = tuning().tail_rays;
     pl.rec4 = pl.sliced ? 6 : 4;
     P.npix = (uint32_t)pl.npix;
     pl.W = W;
@@ -386,7 +455,7 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
 // Samples per chunk: as many as `max_items` pixel samples allow (the tail of deep bounces is paid once per chunk), and
 // few enough that the colour slot s * npix + pixel of every sample stays a 32-bit number.
 int chunk_samples(const Plan &pl, size_t max_items) {
-    int S = pl.count < kChunkSamples ? pl.count : kChunkSamples;
+    int S = pl.count < tuning().chunk_samples ? pl.count : tuning().chunk_samples;
     if (pl.items_per_sample > 0 && (size_t)S * pl.items_per_sample > max_items)
         S = (int)(max_items / pl.items_per_sample);
     if ((size_t)S * pl.npix > 0xFFFFFFFFull)
@@ -419,9 +488,10 @@ int launch_nested(rt_ctx *ctx, const Plan &pl, hipStream_t stream) {
 // pixel, one launch per bounce level (or round), their colours left in ws.colors.  The caller folds them.
 int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t stream, int done, int s_now, KParams &P) {
     P = pl.P;
-    const int levels = pl.levels;
+    const int first_level = pl.camera ? 1 : 0, levels = pl.levels + first_level;
     RT_HIP_CHECK(ctx, hipMemsetAsync(ws.levels, 0, (size_t)(levels + 1) * kSubQueues * 32 * sizeof(unsigned int), stream));
     P.colors = ws.colors;
+    P.deferred = ws.deferred;
     P.S = s_now;
     P.div_per_tile = make_fastdiv(64u * (uint32_t)s_now);
     P.chunk_first = pl.first + done;
@@ -430,7 +500,34 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
     const bool sliced = pl.sliced, queued = pl.queued, refill = pl.refill;
     const int walk = pl.walk;
     dim3 block(256);
-    for (int level = 0; level < levels; level++) {
+    if (pl.camera) { // level 0: camera rays, root slab test; what passes goes to level 1's queue
+        P.level = 0;
+        P.tail = 0;
+        P.q_in = ws.q[0];
+        P.q_out = ws.q[1];
+        P.sub_in = ws.levels;
+        P.sub_cursor = ws.levels + 1;
+        P.sub_out = ws.levels + (size_t)kSubQueues * 32;
+        uint32_t blocks = pl.full_grid;
+        if (blocks > (P.n_my_tiles + 3) / 4)
+            blocks = (P.n_my_tiles + 3) / 4;
+        if (blocks < 1)
+            blocks = 1;
+        dim3 grid(blocks);
+        const int v = (pl.variant & 3) * 2 + (pl.rec4 == 6 ? 1 : 0);
+        switch (v) {
+        case 0: hipLaunchKernelGGL((k_camera<false, false, 4>), grid, block, 0, stream, P); break;
+        case 1: hipLaunchKernelGGL((k_camera<false, false, 6>), grid, block, 0, stream, P); break;
+        case 2: hipLaunchKernelGGL((k_camera<false, true, 4>), grid, block, 0, stream, P); break;
+        case 3: hipLaunchKernelGGL((k_camera<false, true, 6>), grid, block, 0, stream, P); break;
+        case 4: hipLaunchKernelGGL((k_camera<true, false, 4>), grid, block, 0, stream, P); break;
+        case 5: hipLaunchKernelGGL((k_camera<true, false, 6>), grid, block, 0, stream, P); break;
+        case 6: hipLaunchKernelGGL((k_camera<true, true, 4>), grid, block, 0, stream, P); break;
+        default: hipLaunchKernelGGL((k_camera<true, true, 6>), grid, block, 0, stream, P); break;
+        }
+        RT_HIP_CHECK(ctx, hipGetLastError());
+    }
+    for (int level = first_level; level < levels; level++) {
         P.level = level;
         P.tail = level == levels - 1 ? 1 : 0;
         P.q_in = ws.q[level & 1];
@@ -469,23 +566,27 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
 }
 
 int launch_fold(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t stream, const KParams &P) {
-    hipLaunchKernelGGL(k_fold, dim3((unsigned)((pl.npix + 255) / 256)), dim3(256), 0, stream, P.image, ws.colors, (uint32_t)pl.npix,
-                       pl.W, P.tiles_x, P.tile_rank, P.tile_world, P.chunk_first, P.S);
+    if (pl.variant & 2)
+        hipLaunchKernelGGL((k_fold<true>), dim3((unsigned)((pl.npix + 255) / 256)), dim3(256), 0, stream, P);
+    else
+        hipLaunchKernelGGL((k_fold<false>), dim3((unsigned)((pl.npix + 255) / 256)), dim3(256), 0, stream, P);
     RT_HIP_CHECK(ctx, hipGetLastError());
     return RT_OK;
 }
 
 // Gives a pipe's workspace room for chunks of `need_colors` colours and queues of `need_q4` float4 (allocates; the pipe's
 // stream is drained first when buffers have to be replaced).
-int ensure_workspace(rt_ctx *ctx, rt_ctx::Pipe &pp, size_t need_colors, size_t need_q4) {
+int ensure_workspace(rt_ctx *ctx, rt_ctx::Pipe &pp, size_t need_colors, size_t need_q4, size_t need_pixels) {
     Workspace &ws = pp.ws;
-    if (need_colors <= ws.colors_cap && need_q4 <= ws.q_cap)
+    if (need_colors <= ws.colors_cap && need_q4 <= ws.q_cap && need_pixels <= ws.deferred_cap)
         return RT_OK;
     RT_HIP_CHECK(ctx, hipStreamSynchronize(pp.stream));
     if (need_colors < ws.colors_cap)
         need_colors = ws.colors_cap;
     if (need_q4 < ws.q_cap)
         need_q4 = ws.q_cap;
+    if (need_pixels < ws.deferred_cap)
+        need_pixels = ws.deferred_cap;
     unsigned int *levels = ws.levels;
     ws.levels = nullptr;
     free_workspace(ws);
@@ -493,8 +594,10 @@ int ensure_workspace(rt_ctx *ctx, rt_ctx::Pipe &pp, size_t need_colors, size_t n
     RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.colors, (need_colors ? need_colors : 1) * sizeof(float4)));
     RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.q[0], (need_q4 ? need_q4 : 1) * sizeof(float4)));
     RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.q[1], (need_q4 ? need_q4 : 1) * sizeof(float4)));
+    RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.deferred, (need_pixels ? need_pixels : 1) * sizeof(unsigned long long)));
     ws.colors_cap = need_colors;
     ws.q_cap = need_q4;
+    ws.deferred_cap = need_pixels;
     return RT_OK;
 }
 
@@ -537,7 +640,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         rt_ctx::Pipe &pp = ctx->pipes[ctx->next_pipe];
         ctx->next_pipe ^= 1;
         {
-            const int wrc = ensure_workspace(ctx, pp, need_colors, need_q4);
+            const int wrc = ensure_workspace(ctx, pp, need_colors, need_q4, pl.npix);
             if (wrc != RT_OK)
                 return wrc;
         }
@@ -601,8 +704,10 @@ int launch_trace_noalloc(rt_ctx *ctx, int W, int H, int first, int count, float4
     Workspace ws;
     ws.levels = (unsigned int *)base;
     ws.colors = (float4 *)(base + kScratchLevelsBytes);
-    ws.q[0] = (float4 *)(base + kScratchLevelsBytes + kScratchColorsBytes);
-    ws.q[1] = (float4 *)(base + kScratchLevelsBytes + kScratchColorsBytes + kScratchQueueBytes);
+    ws.deferred = (unsigned long long *)(base + kScratchLevelsBytes + kScratchColorsBytes);
+    ws.q[0] = (float4 *)(base + kScratchLevelsBytes + kScratchColorsBytes + kScratchDeferredBytes);
+    ws.q[1] = (float4 *)(base + kScratchLevelsBytes + kScratchColorsBytes + kScratchDeferredBytes + kScratchQueueBytes);
+    ws.deferred_cap = kScratchMaxItems;
     ws.colors_cap = kScratchMaxItems;
     ws.q_cap = (kScratchMaxItems + kQueueSlack) * 6;
     const int S = chunk_samples(pl, kScratchMaxItems); // S * npix <= S * items <= kScratchMaxItems: the colours fit too
@@ -711,6 +816,11 @@ int upload_layout(rt_ctx *ctx, const SceneLayout &L) {
         return rc;
     }
     ctx->expected_visits = L.expected_visits;
+    if (L.fn.size() >= 2) {
+        const float4 a = L.fn[0], b = L.fn[1];
+        const float rb[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+        std::memcpy(ctx->root_box, rb, sizeof(rb));
+    }
     ctx->fast_exact = L.nested;
     ctx->scene_bytes = (L.fn.size() + L.tp.size()) * sizeof(float4);
     ctx->n_nodes = L.n_ref;
@@ -723,7 +833,8 @@ bool options_ok(const rt_options *opt) {
     return !(opt->bounce_limit < 0 || opt->bounce_limit > kMaxLevels - 2 || opt->tile_world < 1 || opt->tile_rank < 0 ||
              opt->tile_rank >= opt->tile_world || (opt->estimator != RT_EST_SD_LOOP && opt->estimator != RT_EST_OLD_RECURSIVE) ||
              opt->traversal < 0 || opt->traversal > RT_TRAV_FAST_SLICED ||
-             (opt->multi_split != RT_SPLIT_TILE && opt->multi_split != RT_SPLIT_SAMPLE));
+             (opt->multi_split != RT_SPLIT_TILE && opt->multi_split != RT_SPLIT_SAMPLE) || opt->camera_stage < 0 ||
+             opt->camera_stage > RT_CAMERA_FUSED);
 }
 
 void destroy_single(rt_ctx *ctx) {
@@ -768,7 +879,7 @@ int create_single(rt_ctx **out, int device) {
     rt_ctx *ctx = new rt_ctx();
     ctx->device = device;
     std::memset(&ctx->cam, 0, sizeof(ctx->cam));
-    ctx->opt = rt_options{4, RT_EST_SD_LOOP, 1u, 0.001f, 0, 1, 0, 0u, RT_TRAV_AUTO, RT_SPLIT_TILE};
+    ctx->opt = rt_options{4, RT_EST_SD_LOOP, 1u, 0.001f, 0, 1, 0, 0u, RT_TRAV_AUTO, RT_SPLIT_TILE, RT_CAMERA_AUTO};
     DeviceGuard g(device);
     auto bail = [&](const char *what) { // whatever exists by now is released the way rt_destroy releases it
         std::fprintf(stderr, "rt_create: %s failed\n", what);
@@ -967,6 +1078,19 @@ void rt_free_host(void *ptr) {
         (void)hipHostFree(ptr);
 }
 
+void rt_vec_op(int op, const float *a, const float *b, const float *c, const float *v, float *out3) {
+    const f3 A = a ? mk3(a[0], a[1], a[2]) : mk3(0, 0, 0), B = b ? mk3(b[0], b[1], b[2]) : mk3(0, 0, 0),
+             C = c ? mk3(c[0], c[1], c[2]) : mk3(0, 0, 0), X = v ? mk3(v[0], v[1], v[2]) : mk3(0, 0, 0);
+    f3 r = mk3(0, 0, 0);
+    switch (op) {
+    case 0: r.x = dot3(A, B); break;
+    case 1: r = cross3(A, B); break;
+    case 2: r = normalize3(A); break;
+    default: r = basis_mul(A, B, C, X); break;
+    }
+    out3[0] = r.x, out3[1] = r.y, out3[2] = r.z;
+}
+
 const char *rt_version(void) { return "rt_hip 0.2 gfx950"; }
 
 int rt_create(rt_ctx **out, int device) {
@@ -1089,7 +1213,7 @@ int rt_reserve(rt_ctx *ctx, int width, int height, int n_samples) {
         const size_t need_colors = (size_t)S * pl.npix, need_q4 = queue_records((size_t)S * pl.items_per_sample) * 6;
         const int chunks = (n_samples + S - 1) / S;
         for (int p = 0; p < (chunks > 1 || c->pipelining ? 2 : 1); p++) {
-            const int rc = ensure_workspace(c, c->pipes[p], need_colors, need_q4);
+            const int rc = ensure_workspace(c, c->pipes[p], need_colors, need_q4, pl.npix);
             if (rc != RT_OK)
                 return rc;
         }

@@ -1,4 +1,4 @@
-// rt_kernels.hpp: path state, shading, camera rays, and the wavefront kernels k_path, k_refill, k_fold -- part of rt_hip.hip (included there, inside its unnamed namespace); see that file for the overall design.
+// rt_kernels.hpp: path state, shading, camera rays, the first-generation kernel k_trace and the wavefront kernels k_camera, k_path, k_refill, k_sliced, k_fold -- part of rt_hip.hip (included there, inside its unnamed namespace); see that file for the overall design.
 #pragma once
 
 // Path state carried from one bounce level to the next.
@@ -10,16 +10,16 @@ struct Path {
     uint32_t key; // RNG key of (pixel, sample)
 };
 
-// Shades one finished closest-hit search: the path either ENDS (its colour goes to colors[sample][pixel]; returns
-// true) or CONTINUES with a new ray in `path` (returns false).  Also records the primary-hit id of the first sample.
+// Shades one finished closest-hit search -- one step of either radiance estimator of CPURayTrace/Trace.cpp: the path either
+// ENDS (returns true; `c` is the sample's colour) or CONTINUES with a new ray in `path` (returns false).  `prim` receives
+// the primitive hit (kNone for a miss).
 template <bool OLD, bool STATS>
-RT_D bool shade_path(const KParams &P, Path &path, const Best &hit, const uint32_t cidx, Cnt &cnt) {
+RT_D bool shade_step(const KParams &P, Path &path, const Best &hit, Cnt &cnt, float4 &c, uint32_t &prim) {
     bool ended = false;
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    c = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t dim = 3u + 4u * (uint32_t)path.depth;
-    const bool first = path.depth == 0;
     path.depth++;
-    uint32_t prim = kNone;
+    prim = kNone;
     if (!OLD) { // Trace::CastRay(ray, depth, sd::DataStorage&), CPURayTrace/Trace.cpp:58-96
         if (hit.ref != kNone) {
             if (STATS)
@@ -122,11 +122,63 @@ RT_D bool shade_path(const KParams &P, Path &path, const Best &hit, const uint32
             }
         }
     }
+    return ended;
+}
+
+// shade_step for the wavefront kernels: an ended path's colour goes to colors[sample][pixel], and the primitive met by the
+// camera ray of the call's first sample to the primary-id image.
+template <bool OLD, bool STATS>
+RT_D bool shade_path(const KParams &P, Path &path, const Best &hit, const uint32_t cidx, Cnt &cnt) {
+    const bool first = path.depth == 0;
+    float4 c;
+    uint32_t prim;
+    const bool ended = shade_step<OLD, STATS>(P, path, hit, cnt, c, prim);
     if (first && P.primary != nullptr && P.chunk_first + (int)(cidx / P.npix) == P.first_sample)
         P.primary[cidx % P.npix] = prim;
     if (ended)
         P.colors[cidx] = c;
     return ended;
+}
+
+// Direction and RNG key of sample n (1-based) of pixel (x, y): CPUImageData::uvAt, Renderer/TraceMethods.hpp:30;
+// Camera::getRayDirction, Camera.hpp:33-47; the jitter of Renderer/TraceMethods.cpp:51-53.
+RT_D void camera_ray(const KParams &P, const int x, const int y, const uint32_t pixel, const int n, uint32_t &key, f3 &dir) {
+    const float u = (float)x / (float)P.W, v = (float)y / (float)P.H;
+    f3 view = normalize3(mk3(u * P.cam_w - P.cam_w / 2, v * P.cam_h - P.cam_h / 2, P.focal));
+    view.x = -view.x;
+    const f3 dir0 = basis_mul(P.bx, P.by, P.bz, view);
+    key = pcg(pcg(P.seed_hash + pixel) + (uint32_t)n + P.sample_offset);
+    // glm::linearRand(vec3(-s), vec3(s)), Include/Random.hpp:13-16
+    const float js = P.jitter;
+    f3 jit = mk3(rng01(key, 0u) * (js - (-js)) + (-js), rng01(key, 1u) * (js - (-js)) + (-js),
+                 rng01(key, 2u) * (js - (-js)) + (-js));
+    dir = dir0 + jit;
+}
+
+// What a camera ray that meets nothing contributes: the colour shade_path stores for a depth-0 path that misses
+// (throughput 1, roulette weight 1).
+template <bool OLD>
+RT_D float4 sky_sample(const f3 d) {
+    const f3 sk = sky_color(d);
+    if (!OLD)
+        return make_float4(0.f + 1.f * sk.x, 0.f + 1.f * sk.y, 0.f + 1.f * sk.z, 0.f + 1.0f);
+    return make_float4((1.f * sk.x) * 1.0f, (1.f * sk.y) * 1.0f, (1.f * sk.z) * 1.0f, (1.f * 1.0f) * 1.0f);
+}
+
+// The slab test of the fast walk (closest = +inf) against the root record of the fast tree: does the walk of this ray
+// get past its first record at all?
+RT_D bool meets_root_box(const KParams &P, const f3 o, const f3 inv) {
+    const float4 a = P.fnodes[0], b = P.fnodes[1];
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
+    const float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
+    const float t0z = (a.z - o.z) * inv.z, t1z = (b.y - o.z) * inv.z;
+    const float nearx = nx ? t1x : t0x, farx = nx ? t0x : t1x;
+    const float neary = ny ? t1y : t0y, fary = ny ? t0y : t1y;
+    const float nearz = nz ? t1z : t0z, farz = nz ? t0z : t1z;
+    const float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+    const float tmax = fminf(farz, fminf(fary, fminf(farx, __builtin_inff())));
+    return !(tmax <= tmin);
 }
 
 // Camera ray of work item `item` = (tile ordinal, sample in chunk, pixel in the 8x8 tile); returns false for a pixel
@@ -145,18 +197,8 @@ RT_D bool camera_path(const KParams &P, const uint32_t item, Path &path, uint32_
     const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
     const int n = P.chunk_first + (int)s;
     cidx = s * P.npix + pixel;
-    // CPUImageData::uvAt, Renderer/TraceMethods.hpp:30; Camera::getRayDirction, Camera.hpp:33-47
-    const float u = (float)x / (float)P.W, v = (float)y / (float)P.H;
-    f3 view = normalize3(mk3(u * P.cam_w - P.cam_w / 2, v * P.cam_h - P.cam_h / 2, P.focal));
-    view.x = -view.x;
-    const f3 dir0 = basis_mul(P.bx, P.by, P.bz, view);
-    path.key = pcg(pcg(P.seed_hash + pixel) + (uint32_t)n + P.sample_offset);
-    // glm::linearRand(vec3(-s), vec3(s)), Include/Random.hpp:13-16
-    const float js = P.jitter;
-    f3 jit = mk3(rng01(path.key, 0u) * (js - (-js)) + (-js), rng01(path.key, 1u) * (js - (-js)) + (-js),
-                 rng01(path.key, 2u) * (js - (-js)) + (-js));
     path.o = P.cam_pos;
-    path.d = dir0 + jit;
+    camera_ray(P, x, y, pixel, n, path.key, path.d);
     path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
     path.rr = 1.0f;
     path.depth = 0;
@@ -169,6 +211,74 @@ RT_D bool camera_path(const KParams &P, const uint32_t item, Path &path, uint32_
         live = false;
     }
     return live;
+}
+
+// First-generation kernel (RT_TRAV_NESTED), kept as an independent schedule of the same arithmetic.  Persistent wave64:
+// each wave draws 8x8-pixel tiles from one atomic counter; a lane owns one pixel of the tile and runs that pixel's samples
+// in order -- every sample's path to its end, closest hit by the per-lane reference-order walk, shading by shade_step --
+// which keeps the reference's running mean "pixel = (pixel*(n-1) + new)/n" (Renderer/TraceMethods.cpp:59) in registers.
+// Finished lanes drop out of the wave's exec mask; the wave leaves a loop when the mask is empty.
+template <bool OLD, bool STATS>
+__global__ void __launch_bounds__(256) k_trace(const KParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    for (;;) {
+        unsigned int j = 0;
+        if (lane == 0)
+            j = atomicAdd(P.queue, 1u);
+        j = __builtin_amdgcn_readfirstlane(j);
+        if (j >= P.n_my_tiles)
+            break;
+        const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
+        const int x = (int)(tile % (uint32_t)P.tiles_x) * 8 + (int)(lane & 7u);
+        const int y = (int)(tile / (uint32_t)P.tiles_x) * 8 + (int)(lane >> 3);
+        if (x < P.W && y < P.H) {
+            const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+            float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (P.first_sample > 1)
+                px = P.image[pixel];
+            for (int n = P.first_sample; n < P.first_sample + P.n_samples; n++) {
+                Path path;
+                path.o = P.cam_pos;
+                camera_ray(P, x, y, pixel, n, path.key, path.d);
+                path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
+                path.rr = 1.0f;
+                path.depth = 0;
+                uint32_t prim = kNone, first_prim = kNone;
+                float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                bool ended = !OLD && P.bounce_limit <= 0; // Trace.cpp:63: no traversal at all, the sample is (0,0,0,0)
+                while (!ended) {
+                    path.inv = mk3(1.0f / path.d.x, 1.0f / path.d.y, 1.0f / path.d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
+                    Best hit;
+                    cnt.rays++;
+                    closest_hit<OLD, STATS>(P, path.o, path.d, path.inv, hit, cnt);
+                    const bool first = path.depth == 0;
+                    ended = shade_step<OLD, STATS>(P, path, hit, cnt, c, prim);
+                    if (first)
+                        first_prim = prim;
+                }
+                if (P.primary != nullptr && n == P.first_sample)
+                    P.primary[pixel] = first_prim;
+                const float nm1 = static_cast<float>((float)n - 1.f), nf = static_cast<float>(n);
+                px = make_float4((px.x * nm1 + c.x) / nf, (px.y * nm1 + c.y) / nf, (px.z * nm1 + c.z) / nf,
+                                 (px.w * nm1 + c.w) / nf);
+            }
+            P.image[pixel] = px;
+        }
+    }
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    unsigned long long r = wave_sum(cnt.rays);
+    if (lane == 0 && r != 0ull)
+        atomicAdd(counter_slot(P, wave_id, 0), r);
+    if (STATS) {
+        unsigned long long b = wave_sum(cnt.box), t = wave_sum(cnt.tri), s = wave_sum(cnt.sph), h = wave_sum(cnt.trih);
+        if (lane == 0 && r != 0ull) {
+            atomicAdd(counter_slot(P, wave_id, 1), b);
+            atomicAdd(counter_slot(P, wave_id, 2), t);
+            atomicAdd(counter_slot(P, wave_id, 3), s);
+            atomicAdd(counter_slot(P, wave_id, 4), h);
+        }
+    }
 }
 
 // Wavefront path kernel: one launch per bounce level.
@@ -212,7 +322,7 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : (WALK == WALK_QUE
     // Tail mode: when a level holds too few rays to fill the chip, its launch lasts as long as its single longest
     // walk, and so would every launch after it; instead each lane then follows its path to the end, and the launches
     // of the deeper levels find their queues empty and return at once.
-    const bool tail = P.tail != 0 || (P.level >= 1 && n_in <= kTailRays);
+    const bool tail = P.tail != 0 || (P.level >= 1 && n_in <= P.tail_rays);
     // Batches of 64 items are dealt to the waves round-robin: one shared cursor would be hit by half a million
     // same-address atomics per launch at level 0, which alone takes longer than the rays.  Neighbouring
     // batches (the samples of one tile, tiles of one image row) go to different waves, so the expensive part of
@@ -398,7 +508,7 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
     }
     if (n_batches == 0u)
         return;
-    const bool tail = P.tail != 0 || (P.level >= 1 && n_batches * 64u <= kTailRays);
+    const bool tail = P.tail != 0 || (P.level >= 1 && n_batches * 64u <= P.tail_rays);
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t my_q = wave_id & (uint32_t)(kSubQueues - 1);
     const uint32_t my_count = P.level == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sub_count, (int)my_q);
@@ -745,29 +855,130 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
         atomicAdd(counter_slot(P, wave_id, 5), rp);
 }
 
-// Folds the S per-sample colours of every owned pixel into the running mean, in sample order:
-// pixel = (pixel*(n-1) + colour_n)/n, Renderer/TraceMethods.cpp:59.
-__global__ void __launch_bounds__(256) k_fold(float4 *image, const float4 *colors, uint32_t npix, int W, int tiles_x,
-                                              int tile_rank, int tile_world, int chunk_first, int S) {
+// Camera stage of a chunk (launched instead of level 0 of the path kernels when the scene covers little of the frame).
+//
+// Most camera rays of such a frame fail the walk's very first slab test -- the root record of the fast tree -- and end as
+// sky.  Giving each of them a queue slot, a colour slot and a lane of the path kernel costs more than the ray: 32 bytes of
+// HBM traffic per sample, and the wave's walk machinery for one record.  Here a wave takes an 8x8 tile and each lane runs
+// through the chunk's S samples of its pixel: camera ray, root slab test.  Only the samples that pass go to the queue (as
+// walks that have not started; the path kernels take them from level 1 on); the others are noted as a clear bit in the
+// pixel's `deferred` word and never touch memory again: k_fold regenerates their ray and folds the sky colour where their
+// turn in the sample order comes.  One queue reservation per tile (none for a tile that is all sky); records are
+// sample-major within it, so a batch of the next level holds neighbouring pixels of one sample.
+template <bool OLD, bool STATS, int REC4>
+__global__ void __launch_bounds__(256) k_camera(const KParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    unsigned long long n_sky = 0ull;
+    for (uint32_t j = wave_id; j < P.n_my_tiles; j += n_waves) {
+        const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
+        const uint32_t tile_y = fastdiv(tile, P.div_tiles_x);
+        const int x = (int)(tile - tile_y * (uint32_t)P.tiles_x) * 8 + (int)(lane & 7u);
+        const int y = (int)tile_y * 8 + (int)(lane >> 3);
+        const bool live = x < P.W && y < P.H;
+        const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+        unsigned long long mask = 0ull;
+        if (live) {
+            for (int s = 0; s < P.S; s++) {
+                uint32_t key;
+                f3 d;
+                camera_ray(P, x, y, pixel, P.chunk_first + s, key, d);
+                const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
+                if (meets_root_box(P, P.cam_pos, inv))
+                    mask |= 1ull << s;
+            }
+            P.deferred[pixel] = mask;
+            n_sky += (unsigned long long)(P.S - __builtin_popcountll(mask));
+            if (P.primary != nullptr && P.chunk_first == P.first_sample && !(mask & 1ull))
+                P.primary[pixel] = kNone;
+        }
+        // ---- the samples that get past the root box: one reservation for the tile, records sample-major ----
+        uint32_t mine = (uint32_t)__builtin_popcountll(mask), total = mine;
+        for (int off = 32; off > 0; off >>= 1)
+            total += (uint32_t)__shfl_xor((int)total, off, 64);
+        if (total == 0u)
+            continue;
+        const uint32_t q = j & (uint32_t)(kSubQueues - 1);
+        unsigned int base = 0;
+        if (lane == 0)
+            base = atomicAdd(P.sub_out + q * 32u, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+        unsigned int lo32 = (unsigned int)mask, hi32 = (unsigned int)(mask >> 32);
+        for (int off = 32; off > 0; off >>= 1) { // wave-wide OR of the masks: the samples somebody queued
+            lo32 |= (unsigned int)__shfl_xor((int)lo32, off, 64);
+            hi32 |= (unsigned int)__shfl_xor((int)hi32, off, 64);
+        }
+        unsigned long long any = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)hi32) << 32) |
+                                 (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)lo32);
+        while (any != 0ull) {
+            const int s = __builtin_ctzll(any);
+            any &= any - 1ull;
+            const bool has = (mask >> s) & 1ull;
+            const unsigned long long bm = __ballot(has);
+            if (has) {
+                uint32_t key;
+                f3 d;
+                camera_ray(P, x, y, pixel, P.chunk_first + s, key, d);
+                const size_t slot = (size_t)q * P.sub_cap + (size_t)base + (size_t)__builtin_popcountll(bm & below);
+                const uint32_t cidx = (uint32_t)s * P.npix + pixel;
+                P.q_out[REC4 * slot] = make_float4(P.cam_pos.x, P.cam_pos.y, P.cam_pos.z, d.x);
+                P.q_out[REC4 * slot + 1] = make_float4(d.y, d.z, 1.f, 1.f);
+                P.q_out[REC4 * slot + 2] = make_float4(1.f, 1.f, 1.0f, __uint_as_float(key));
+                if (REC4 == 4) {
+                    P.q_out[REC4 * slot + 3] = make_float4(__uint_as_float(cidx), __uint_as_float(0u), 0.f, 0.f);
+                } else { // a walk that has not started: Walk{0, kNone, kNone, 0}, no candidate yet
+                    P.q_out[REC4 * slot + 3] = make_float4(__uint_as_float(cidx), __uint_as_float(0u), __uint_as_float(0u), __uint_as_float(kNone));
+                    P.q_out[REC4 * slot + 4] = make_float4(__builtin_inff(), 0.0f, 0.0f, __uint_as_float(kNone));
+                    P.q_out[REC4 * slot + 5] = make_float4(0.0f, __uint_as_float(kNone), 0.0f, __uint_as_float(kNone));
+                }
+            }
+            base += (unsigned int)__builtin_popcountll(bm);
+        }
+    }
+    // a sample that ends here is one closest-hit search of one slab test
+    const unsigned long long r = wave_sum(n_sky);
+    if (lane == 0 && r != 0ull) {
+        atomicAdd(counter_slot(P, wave_id, 0), r);
+        if (STATS)
+            atomicAdd(counter_slot(P, wave_id, 1), r);
+    }
+}
+
+// Folds the S samples of every owned pixel into the running mean, in sample order:
+// pixel = (pixel*(n-1) + colour_n)/n, Renderer/TraceMethods.cpp:59.  A sample's colour comes from the per-sample colour
+// buffer, or -- camera stage, sample not deferred -- is the sky seen by its camera ray, worked out here.
+template <bool OLD>
+__global__ void __launch_bounds__(256) k_fold(const KParams P) {
     const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
-    if (pixel >= npix)
+    if (pixel >= P.npix)
         return;
-    if (tile_world > 1) {
-        const uint32_t x = pixel % (uint32_t)W, y = pixel / (uint32_t)W;
-        const uint32_t tile = (y >> 3) * (uint32_t)tiles_x + (x >> 3);
-        if ((int)(tile % (uint32_t)tile_world) != tile_rank)
+    const uint32_t x = pixel % (uint32_t)P.W, y = pixel / (uint32_t)P.W;
+    if (P.tile_world > 1) {
+        const uint32_t tile = (y >> 3) * (uint32_t)P.tiles_x + (x >> 3);
+        if ((int)(tile % (uint32_t)P.tile_world) != P.tile_rank)
             return;
     }
     float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (chunk_first > 1)
-        px = image[pixel];
-    for (int s = 0; s < S; s++) {
-        const int n = chunk_first + s;
-        const float4 c = colors[(size_t)s * npix + pixel];
+    if (P.chunk_first > 1)
+        px = P.image[pixel];
+    const unsigned long long mask = P.camera_stage ? P.deferred[pixel] : ~0ull;
+    for (int s = 0; s < P.S; s++) {
+        const int n = P.chunk_first + s;
+        float4 c;
+        if ((mask >> s) & 1ull) {
+            c = P.colors[(size_t)s * P.npix + pixel];
+        } else {
+            uint32_t key;
+            f3 d;
+            camera_ray(P, (int)x, (int)y, pixel, n, key, d);
+            c = sky_sample<OLD>(d);
+        }
         const float nm1 = static_cast<float>((float)n - 1.f), nf = static_cast<float>(n);
         px = make_float4((px.x * nm1 + c.x) / nf, (px.y * nm1 + c.y) / nf, (px.z * nm1 + c.z) / nf, (px.w * nm1 + c.w) / nf);
     }
-    image[pixel] = px;
+    P.image[pixel] = px;
 }
 
 // Several devices behind one context, tile split: `src` is the frame as device `rank` of `world` rendered it (its own

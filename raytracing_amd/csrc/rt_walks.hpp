@@ -1,4 +1,4 @@
-// rt_walks.hpp: closest-hit searches (reference-order lane / wave walks, brute force, the fast walk and its ordered replay) and the first-generation kernel k_trace -- part of rt_hip.hip (included there, inside its unnamed namespace); see that file for the overall design.
+// rt_walks.hpp: closest-hit searches (reference-order lane / wave walks, brute force, the fast walk and its ordered replay) -- part of rt_hip.hip (included there, inside its unnamed namespace); see that file for the overall design.
 #pragma once
 
 struct Best {
@@ -8,6 +8,47 @@ struct Best {
 struct Cnt {
     unsigned long long rays, box, tri, sph, trih, replay;
 };
+
+// Moller-Trumbore exactly as sd::IntersectTriangle (SimplifiedData.cpp:269-307) and Triangle::intersect (Mesh.hpp:39-77)
+// evaluate it, on the stored p0, e1 = p1 - p0, e2 = p2 - p0: true when the test reports a hit (t > EPSILON; the caller
+// applies its own "closer than" rule), with the hit's t, u, v.
+RT_D bool tri_test(const f3 o, const f3 d, const f3 p0, const f3 e1, const f3 e2, float &t, float &u, float &v) {
+    const float EPSILON = 1e-7f;
+    const f3 h = cross3(d, e2);
+    const float det = dot3(e1, h);
+    if (det > -EPSILON && det < EPSILON)
+        return false;
+    const float f = 1.0f / det;
+    const f3 s = o - p0;
+    u = f * dot3(s, h);
+    if (u < 0.0f || u > 1.0f)
+        return false;
+    const f3 q = cross3(s, e1);
+    v = f * dot3(d, q);
+    if (v < 0.0f || u + v > 1.0f)
+        return false;
+    t = f * dot3(e2, q);
+    return t > EPSILON;
+}
+
+// Sphere::intersect (Objects.hpp:43-72): the near root, and a ray that starts inside never hits -- except for the
+// dielectric spheres this build adds (`dielectric`), which need the exit point.  True with t when the test reports a hit.
+RT_D bool sphere_test(const f3 o, const f3 d, const float4 s0, const bool dielectric, float &t) {
+    const f3 oc = mk3(s0.x, s0.y, s0.z) - o;
+    const float qa = dot3(d, d);
+    const float qb = -2.0f * dot3(d, oc);
+    const float qc = dot3(oc, oc) - s0.w * s0.w;
+    const float disc = qb * qb - 4 * qa * qc;
+    if (disc < 0)
+        return false;
+    t = (-qb - sqrtf(disc)) / (2.0f * qa);
+    bool ok = !(t < 0);
+    if (!ok && dielectric) {
+        t = (-qb + sqrtf(disc)) / (2.0f * qa);
+        ok = !(t < 0);
+    }
+    return ok;
+}
 
 // Closest hit in the reference's own visiting order.  One iteration = one node of the reference
 // traversal: slab test against (1e-6, closest.t) (SimplifiedData.cpp:443, BVH.hpp:129), then for a
@@ -63,49 +104,21 @@ RT_D void closest_hit(const KParams &P, const f3 o, const f3 d, const f3 inv, Be
                 cnt.tri++;
             const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
             const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
-            const float EPSILON = 1e-7f;
-            f3 h = cross3(d, e2);
-            float det = dot3(e1, h);
-            if (!(det > -EPSILON && det < EPSILON)) {
-                float f = 1.0f / det;
-                f3 s = o - p0;
-                float u = f * dot3(s, h);
-                if (!(u < 0.0f || u > 1.0f)) {
-                    f3 q = cross3(s, e1);
-                    float v = f * dot3(d, q);
-                    if (!(v < 0.0f || u + v > 1.0f)) {
-                        float t = f * dot3(e2, q);
-                        if (t > EPSILON && t < best.t) {
-                            best.t = t;
-                            best.u = u;
-                            best.v = v;
-                            best.ref = slot;
-                        }
-                    }
-                }
+            float t, u, v;
+            if (tri_test(o, d, p0, e1, e2, t, u, v) && t < best.t) {
+                best.t = t;
+                best.u = u;
+                best.v = v;
+                best.ref = slot;
             }
         } else if (OLD && k == KIND_SPHERE) { // Sphere::intersect, Objects.hpp:43-72
             if (STATS)
                 cnt.sph++;
             const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
-            f3 oc = mk3(s0.x, s0.y, s0.z) - o;
-            float qa = dot3(d, d);
-            float qb = -2.0f * dot3(d, oc);
-            float qc = dot3(oc, oc) - s0.w * s0.w;
-            float disc = qb * qb - 4 * qa * qc;
-            if (!(disc < 0)) {
-                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
-                bool ok = !(t < 0);
-                // a ray that starts inside never hits (Objects.hpp:57-60), except for the dielectric
-                // spheres this build adds, which need the exit point
-                if (!ok && __float_as_uint(s1.z) != 0u) {
-                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
-                    ok = !(t < 0);
-                }
-                if (ok && t < best.t) {
-                    best.t = t;
-                    best.ref = kSphereBit | slot;
-                }
+            float t;
+            if (sphere_test(o, d, s0, __float_as_uint(s1.z) != 0u, t) && t < best.t) {
+                best.t = t;
+                best.ref = kSphereBit | slot;
             }
         } else if (OLD && k == KIND_MESH) { // Mesh::intersect starts a fresh closest hit (Mesh.hpp:154-160)
             outer = best;
@@ -154,47 +167,23 @@ RT_D void closest_hit_brute(const KParams &P, const f3 o, const f3 d, Best &best
                 cnt.tri++;
             const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
             const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
-            const float EPSILON = 1e-7f;
-            f3 h = cross3(d, e2);
-            float det = dot3(e1, h);
-            if (!(det > -EPSILON && det < EPSILON)) {
-                float f = 1.0f / det;
-                f3 s = o - p0;
-                float u = f * dot3(s, h);
-                if (!(u < 0.0f || u > 1.0f)) {
-                    f3 q = cross3(s, e1);
-                    float v = f * dot3(d, q);
-                    if (!(v < 0.0f || u + v > 1.0f)) {
-                        float t = f * dot3(e2, q);
-                        const uint32_t ti = __float_as_uint(q2.y);
-                        const bool in_order_group = !OLD || inner_end != kNone; // triangles scanned in storage order
-                        if (t > EPSILON && (t < best.t || (in_order_group && t == best.t && t < __builtin_inff() && ti < bidx))) {
-                            best = Best{t, u, v, slot};
-                            bidx = ti;
-                        }
-                    }
+            float t, u, v;
+            if (tri_test(o, d, p0, e1, e2, t, u, v)) {
+                const uint32_t ti = __float_as_uint(q2.y);
+                const bool in_order_group = !OLD || inner_end != kNone; // triangles scanned in storage order
+                if (t < best.t || (in_order_group && t == best.t && t < __builtin_inff() && ti < bidx)) {
+                    best = Best{t, u, v, slot};
+                    bidx = ti;
                 }
             }
         } else if (OLD && k == KIND_SPHERE) { // Sphere::intersect, Objects.hpp:43-72
             if (STATS)
                 cnt.sph++;
             const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
-            f3 oc = mk3(s0.x, s0.y, s0.z) - o;
-            float qa = dot3(d, d);
-            float qb = -2.0f * dot3(d, oc);
-            float qc = dot3(oc, oc) - s0.w * s0.w;
-            float disc = qb * qb - 4 * qa * qc;
-            if (!(disc < 0)) {
-                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
-                bool ok = !(t < 0);
-                if (!ok && __float_as_uint(s1.z) != 0u) {
-                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
-                    ok = !(t < 0);
-                }
-                if (ok && t < best.t) {
-                    best = Best{t, 0.0f, 0.0f, kSphereBit | slot};
-                    bidx = kNone;
-                }
+            float t;
+            if (sphere_test(o, d, s0, __float_as_uint(s1.z) != 0u, t) && t < best.t) {
+                best = Best{t, 0.0f, 0.0f, kSphereBit | slot};
+                bidx = kNone;
             }
         } else if (OLD && k == KIND_MESH) { // Mesh::intersect starts a fresh closest hit (Mesh.hpp:154-160)
             outer = best;
@@ -211,15 +200,6 @@ RT_D void closest_hit_brute(const KParams &P, const f3 o, const f3 d, Best &best
     }
 }
 
-struct RayState {
-    f3 o, d, inv;
-};
-RT_D void set_ray(RayState &r, f3 o, f3 d) { // Ray::Ray, CPURayTrace/Ray.hpp:8
-    r.o = o;
-    r.d = d;
-    r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-}
-
 RT_D f3 tri_normal(const KParams &P, uint32_t slot, float u, float v) { // SimplifiedData.cpp:293
     const float4 m0 = P.tri_nrm[3 * slot], m1 = P.tri_nrm[3 * slot + 1], m2 = P.tri_nrm[3 * slot + 2];
     const f3 n0 = mk3(m0.x, m0.y, m0.z), n1 = mk3(m0.w, m1.x, m1.y), n2 = mk3(m1.z, m1.w, m2.x);
@@ -234,130 +214,6 @@ RT_D float reflectance(float cosine, float ri) {
     return r0 + (1.0f - r0) * ((m2 * m2) * m);
 }
 
-// One pixel sample with the flat-scene estimator, Trace::CastRay(ray, depth, sd::DataStorage&),
-// CPURayTrace/Trace.cpp:58-96.
-template <bool STATS>
-RT_D float4 sample_sd(const KParams &P, RayState ray, uint32_t key, Cnt &cnt, uint32_t &primary) {
-    float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
-    f3 thr = mk3(1.f, 1.f, 1.f);
-    int depth = 0;
-    while (depth < P.bounce_limit) {
-        const uint32_t dim = 3u + 4u * (uint32_t)depth;
-        depth++;
-        Best hit;
-        cnt.rays++;
-        closest_hit<false, STATS>(P, ray.o, ray.d, ray.inv, hit, cnt);
-        if (hit.ref != kNone) {
-            if (STATS)
-                cnt.trih++;
-            const float4 q2 = P.tri_pos[3 * hit.ref + 2];
-            if (depth == 1)
-                primary = __float_as_uint(q2.y);
-            if (__float_as_uint(q2.z) != 0u)
-                continue; // not LambertianMat: the reference loop re-casts the unchanged ray (Trace.cpp:80-82)
-            f3 N = tri_normal(P, hit.ref, hit.u, hit.v);
-            f3 pos = ray.o + hit.t * ray.d;
-            // Lambertian::Hit, Materials/Lambertian.hpp:35-48
-            f3 bias = N * 1e-5f;
-            float u1 = rng01(key, dim + 1u);
-            float u2 = rng01(key, dim + 2u);
-            f3 nd = cosine_dir(N, u1, u2);
-            set_ray(ray, pos + bias, nd);
-            thr = thr * mk3(0.9f, 0.6f, 0.5f);
-            continue;
-        }
-        if (depth == 1)
-            primary = kNone;
-        f3 add = thr * sky_color(ray.d);
-        color = make_float4(color.x + add.x, color.y + add.y, color.z + add.z, color.w + 1.0f);
-        break;
-    }
-    return color;
-}
-
-// One pixel sample with the old-scene estimator, Trace::CastRay(ray, depth, const Scene&),
-// CPURayTrace/Trace.cpp:31-56, unrolled into a loop: the recursion multiplies albedo and roulette
-// weights on the way back, the loop multiplies them into a running throughput on the way in.
-template <bool STATS>
-RT_D float4 sample_old(const KParams &P, RayState ray, uint32_t key, Cnt &cnt, uint32_t &primary) {
-    float4 thr = make_float4(1.f, 1.f, 1.f, 1.f);
-    for (int depth = 0;; depth++) {
-        const uint32_t dim = 3u + 4u * (uint32_t)depth;
-        float rr = 1.0f; // Trace.cpp:33, Random::RussianRoulette(0.8f), Include/Random.hpp:74-78
-        if (depth > 1)
-            rr = rng01(key, dim) < 0.8f ? 1.0f / 0.8f : 0.0f;
-        if (depth > P.bounce_limit || rr == 0.0f)
-            return make_float4(0.f, 0.f, 0.f, 0.f);
-        Best hit;
-        cnt.rays++;
-        closest_hit<true, STATS>(P, ray.o, ray.d, ray.inv, hit, cnt);
-        if (hit.ref == kNone) {
-            if (depth == 0)
-                primary = kNone;
-            f3 s = sky_color(ray.d);
-            return make_float4((thr.x * s.x) * rr, (thr.y * s.y) * rr, (thr.z * s.z) * rr, (thr.w * 1.0f) * rr);
-        }
-        f3 pos = ray.o + hit.t * ray.d;
-        f3 N;
-        uint32_t mat, prim;
-        if (hit.ref & kSphereBit) {
-            const uint32_t si = hit.ref & ~kSphereBit;
-            const float4 s0 = P.spheres[2 * si], s1 = P.spheres[2 * si + 1];
-            N = normalize3(pos - mk3(s0.x, s0.y, s0.z));
-            mat = __float_as_uint(s1.x);
-            prim = __float_as_uint(s1.y);
-        } else {
-            if (STATS)
-                cnt.trih++;
-            const float4 q2 = P.tri_pos[3 * hit.ref + 2];
-            N = tri_normal(P, hit.ref, hit.u, hit.v);
-            prim = __float_as_uint(q2.y);
-            mat = __float_as_uint(q2.z);
-        }
-        if (depth == 0)
-            primary = prim;
-        const float4 m0 = P.mats[2 * mat], m1 = P.mats[2 * mat + 1];
-        const uint32_t kind = __float_as_uint(m1.x);
-        const float param = m1.y;
-        thr = make_float4((thr.x * m0.x) * rr, (thr.y * m0.y) * rr, (thr.z * m0.z) * rr, (thr.w * m0.w) * rr);
-        if (kind == RT_MAT_EMIT) // LightEmit::getIrradiance, Materials/LightEmit.hpp:11-14
-            return thr;
-        if (kind == RT_MAT_DIELECTRIC) { // no reference counterpart: Snell + Schlick
-            f3 unit = normalize3(ray.d);
-            bool front = dot3(unit, N) < 0.0f;
-            f3 n = front ? N : -N;
-            float ri = front ? (1.0f / param) : param;
-            float dn = dot3(-unit, n);
-            float cosT = (1.0f < dn) ? 1.0f : dn;
-            float sinT = sqrtf(1.0f - cosT * cosT);
-            bool cannot = ri * sinT > 1.0f;
-            float pick = rng01(key, dim + 3u);
-            f3 bias = n * 1e-4f;
-            if (cannot || reflectance(cosT, ri) > pick) {
-                f3 refl = unit - n * dot3(unit, n) * 2.f;
-                set_ray(ray, pos + bias, refl);
-            } else {
-                f3 perp = ri * (unit + cosT * n);
-                f3 par = n * -sqrtf(fabsf(1.0f - dot3(perp, perp)));
-                set_ray(ray, pos - bias, perp + par);
-            }
-            continue;
-        }
-        // Lambertian::getIrradiance (Materials/Lambertian.hpp:16-29) / Metal::getIrradiance (Metal.hpp:15-31)
-        f3 bias = N * 1e-4f;
-        float u1 = rng01(key, dim + 1u);
-        float u2 = rng01(key, dim + 2u);
-        f3 rnd = cosine_dir(N, u1, u2);
-        if (kind == RT_MAT_METAL) {
-            f3 refl = ray.d - N * dot3(ray.d, N) * 2.f;
-            f3 nd = normalize3(rnd * param + refl * (1 - param));
-            set_ray(ray, pos + bias, nd);
-        } else {
-            set_ray(ray, pos + bias, rnd);
-        }
-    }
-}
-
 // Thousands of atomics on ONE address are serialised by the memory system (about 10 ns each: 80 us for one per
 // wave of a full grid), so counters and queue appends are spread over 64 addresses in separate cache lines.
 RT_D unsigned long long *counter_slot(const KParams &P, uint32_t wave_id, int k) {
@@ -368,70 +224,6 @@ RT_D unsigned long long wave_sum(unsigned long long v) {
         v += __shfl_xor(v, off, 64);
     return v;
 }
-
-// Persistent wave64 kernel.  Each wave draws 8x8-pixel tiles from one atomic counter; a lane owns one
-// pixel of the tile and runs that pixel's samples in order, which keeps the reference's running mean
-// "pixel = (pixel*(n-1) + new)/n" (Renderer/TraceMethods.cpp:59) in registers.  Finished lanes drop
-// out of the wave's exec mask; the wave leaves a loop when the mask is empty.
-template <bool OLD, bool STATS>
-__global__ void __launch_bounds__(256) k_trace(const KParams P) {
-    const uint32_t lane = threadIdx.x & 63u;
-    Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-    for (;;) {
-        unsigned int j = 0;
-        if (lane == 0)
-            j = atomicAdd(P.queue, 1u);
-        j = __builtin_amdgcn_readfirstlane(j);
-        if (j >= P.n_my_tiles)
-            break;
-        const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
-        const int x = (int)(tile % (uint32_t)P.tiles_x) * 8 + (int)(lane & 7u);
-        const int y = (int)(tile / (uint32_t)P.tiles_x) * 8 + (int)(lane >> 3);
-        if (x < P.W && y < P.H) {
-            const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
-            float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (P.first_sample > 1)
-                px = P.image[pixel];
-            // CPUImageData::uvAt, Renderer/TraceMethods.hpp:30; Camera::getRayDirction, Camera.hpp:33-47
-            const float u = (float)x / (float)P.W, v = (float)y / (float)P.H;
-            f3 view = normalize3(mk3(u * P.cam_w - P.cam_w / 2, v * P.cam_h - P.cam_h / 2, P.focal));
-            view.x = -view.x;
-            const f3 dir0 = basis_mul(P.bx, P.by, P.bz, view);
-            const uint32_t pkey = pcg(pcg(P.seed) + pixel);
-            for (int n = P.first_sample; n < P.first_sample + P.n_samples; n++) {
-                const uint32_t key = pcg(pkey + (uint32_t)n + P.sample_offset);
-                // glm::linearRand(vec3(-s), vec3(s)), Include/Random.hpp:13-16
-                const float s = P.jitter;
-                f3 jit = mk3(rng01(key, 0u) * (s - (-s)) + (-s), rng01(key, 1u) * (s - (-s)) + (-s),
-                             rng01(key, 2u) * (s - (-s)) + (-s));
-                RayState ray;
-                set_ray(ray, P.cam_pos, dir0 + jit);
-                uint32_t prim = kNone;
-                float4 c = OLD ? sample_old<STATS>(P, ray, key, cnt, prim) : sample_sd<STATS>(P, ray, key, cnt, prim);
-                if (P.primary != nullptr && n == P.first_sample)
-                    P.primary[pixel] = prim;
-                const float nm1 = static_cast<float>((float)n - 1.f), nf = static_cast<float>(n);
-                px = make_float4((px.x * nm1 + c.x) / nf, (px.y * nm1 + c.y) / nf, (px.z * nm1 + c.z) / nf,
-                                 (px.w * nm1 + c.w) / nf);
-            }
-            P.image[pixel] = px;
-        }
-    }
-    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    unsigned long long r = wave_sum(cnt.rays);
-    if (lane == 0 && r != 0ull)
-        atomicAdd(counter_slot(P, wave_id, 0), r);
-    if (STATS) {
-        unsigned long long b = wave_sum(cnt.box), t = wave_sum(cnt.tri), s = wave_sum(cnt.sph), h = wave_sum(cnt.trih);
-        if (lane == 0 && r != 0ull) {
-            atomicAdd(counter_slot(P, wave_id, 1), b);
-            atomicAdd(counter_slot(P, wave_id, 2), t);
-            atomicAdd(counter_slot(P, wave_id, 3), s);
-            atomicAdd(counter_slot(P, wave_id, 4), h);
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Wave-synchronous closest hit.  All lanes of the wave walk the node array together: the wave visits
@@ -446,6 +238,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v8f __attribute__((ext_vector_type(8)));
 typedef const v4f __attribute__((address_space(4))) *cf4ptr; // constant address space: scalar loads
 typedef const v8f __attribute__((address_space(4))) *cf8ptr;
+RT_D float4 mk4(const v4f v) { return make_float4(v.x, v.y, v.z, v.w); }
 
 // OCT >= 0: every live lane's direction has the same sign pattern (the usual case for the camera rays of
 // a tile).  The near/far plane of each axis is then fixed at compile time instead of chosen by six
@@ -538,26 +331,12 @@ RT_D void wave_walk(const KParams &P, const bool live, const f3 o, const f3 d, c
                 if (STATS)
                     cnt.tri++;
                 const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
-                const float EPSILON = 1e-7f;
-                f3 h = cross3(d, e2);
-                float det = dot3(e1, h);
-                if (!(det > -EPSILON && det < EPSILON)) {
-                    float f = 1.0f / det;
-                    f3 sv = o - p0;
-                    float u = f * dot3(sv, h);
-                    if (!(u < 0.0f || u > 1.0f)) {
-                        f3 q = cross3(sv, e1);
-                        float v = f * dot3(d, q);
-                        if (!(v < 0.0f || u + v > 1.0f)) {
-                            float t = f * dot3(e2, q);
-                            if (t > EPSILON && t < best.t) {
-                                best.t = t;
-                                best.u = u;
-                                best.v = v;
-                                best.ref = slot;
-                            }
-                        }
-                    }
+                float t, u, v;
+                if (tri_test(o, d, p0, e1, e2, t, u, v) && t < best.t) {
+                    best.t = t;
+                    best.u = u;
+                    best.v = v;
+                    best.ref = slot;
                 }
             }
         } else if (OLD && k == KIND_SPHERE) {
@@ -565,22 +344,10 @@ RT_D void wave_walk(const KParams &P, const bool live, const f3 o, const f3 d, c
             if (pass) {
                 if (STATS)
                     cnt.sph++;
-                f3 oc = mk3(s0.x, s0.y, s0.z) - o;
-                float qa = dot3(d, d);
-                float qb = -2.0f * dot3(d, oc);
-                float qc = dot3(oc, oc) - s0.w * s0.w;
-                float disc = qb * qb - 4 * qa * qc;
-                if (!(disc < 0)) {
-                    float t = (-qb - sqrtf(disc)) / (2.0f * qa);
-                    bool ok = !(t < 0);
-                    if (!ok && __float_as_uint(s1.z) != 0u) {
-                        t = (-qb + sqrtf(disc)) / (2.0f * qa);
-                        ok = !(t < 0);
-                    }
-                    if (ok && t < best.t) {
-                        best.t = t;
-                        best.ref = kSphereBit | slot;
-                    }
+                float t;
+                if (sphere_test(o, d, mk4(s0), __float_as_uint(s1.z) != 0u, t) && t < best.t) {
+                    best.t = t;
+                    best.ref = kSphereBit | slot;
                 }
             }
         } else if (OLD && k == KIND_MESH) {
@@ -723,44 +490,18 @@ RT_D void fast_walk_from(const KParams &P, const f3 o, const f3 d, const f3 inv,
             // load of p0 behind the determinant test, which puts a second memory round trip into most triangle tests.
             asm volatile("" : : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w), "v"(q2.x));
             const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
-            const float EPSILON = 1e-7f;
-            f3 h = cross3(d, e2);
-            float det = dot3(e1, h);
-            if (!(det > -EPSILON && det < EPSILON)) {
-                float f = 1.0f / det;
-                f3 s = o - p0;
-                float u = f * dot3(s, h);
-                if (!(u < 0.0f || u > 1.0f)) {
-                    f3 q = cross3(s, e1);
-                    float v = f * dot3(d, q);
-                    if (!(v < 0.0f || u + v > 1.0f)) {
-                        float t = f * dot3(e2, q);
-                        if (t > EPSILON)
-                            consider(Cand{t, u, v, tmin, slot, __float_as_uint(q2.w), mesh, mesh_m});
-                    }
-                }
-            }
+            float t, u, v;
+            if (tri_test(o, d, p0, e1, e2, t, u, v))
+                consider(Cand{t, u, v, tmin, slot, __float_as_uint(q2.w), mesh, mesh_m});
         } else if (OLD && k == KIND_SPHERE) {
             if (STATS)
                 cnt.sph++;
             if (note(1u, slot, fmaxf(tmin, 0.0f)))
                 continue;
             const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
-            f3 oc = mk3(s0.x, s0.y, s0.z) - o;
-            float qa = dot3(d, d);
-            float qb = -2.0f * dot3(d, oc);
-            float qc = dot3(oc, oc) - s0.w * s0.w;
-            float disc = qb * qb - 4 * qa * qc;
-            if (!(disc < 0)) {
-                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
-                bool ok = !(t < 0);
-                if (!ok && __float_as_uint(s1.z) != 0u) {
-                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
-                    ok = !(t < 0);
-                }
-                if (ok)
-                    consider(Cand{t, 0.0f, 0.0f, tmin, kSphereBit | slot, __float_as_uint(s1.w), kNone, 0.0f});
-            }
+            float t;
+            if (sphere_test(o, d, s0, __float_as_uint(s1.z) != 0u, t))
+                consider(Cand{t, 0.0f, 0.0f, tmin, kSphereBit | slot, __float_as_uint(s1.w), kNone, 0.0f});
         } else if (OLD && k == KIND_MESH) { // the mesh's inner hierarchy follows inline, up to `skip`
             mesh = slot;
             mesh_m = tmin;
@@ -915,52 +656,26 @@ RT_D void resolve_jobs(const KParams &P, const uint32_t lane, const f3 o, const 
         uint32_t href = slot;
         if (valid && sphere) {
             const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
-            f3 oc = mk3(s0.x, s0.y, s0.z) - ro;
-            float qa = dot3(rd, rd);
-            float qb = -2.0f * dot3(rd, oc);
-            float qc = dot3(oc, oc) - s0.w * s0.w;
-            float disc = qb * qb - 4 * qa * qc;
-            if (!(disc < 0)) {
-                float t = (-qb - sqrtf(disc)) / (2.0f * qa);
-                bool ok = !(t < 0);
-                if (!ok && __float_as_uint(s1.z) != 0u) {
-                    t = (-qb + sqrtf(disc)) / (2.0f * qa);
-                    ok = !(t < 0);
-                }
-                if (ok && t < inf) { // t >= 0 here (NaN fails "t < inf"); -0 takes the key of +0, which it equals
-                    hit = true;
-                    key = ((unsigned long long)(t == 0.0f ? 0u : __float_as_uint(t)) << 32) | (unsigned long long)__float_as_uint(s1.w);
-                    ht = t;
-                    href = kSphereBit | slot;
-                }
+            float t;
+            if (sphere_test(ro, rd, s0, __float_as_uint(s1.z) != 0u, t) && t < inf) { // t >= 0 here (NaN fails "t < inf"); -0 takes the key of +0, which it equals
+                hit = true;
+                key = ((unsigned long long)(t == 0.0f ? 0u : __float_as_uint(t)) << 32) | (unsigned long long)__float_as_uint(s1.w);
+                ht = t;
+                href = kSphereBit | slot;
             }
         } else if (valid) {
             const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
             // the whole record before the test starts, as in fast_walk_from (q2.w, the position, is needed by every hit)
             asm volatile("" : : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w), "v"(q2.x), "v"(q2.w));
             const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
-            const float EPSILON = 1e-7f;
-            f3 h = cross3(rd, e2);
-            float det = dot3(e1, h);
-            if (!(det > -EPSILON && det < EPSILON)) {
-                float f = 1.0f / det;
-                f3 s = ro - p0;
-                float u = f * dot3(s, h);
-                if (!(u < 0.0f || u > 1.0f)) {
-                    f3 q = cross3(s, e1);
-                    float v = f * dot3(rd, q);
-                    if (!(v < 0.0f || u + v > 1.0f)) {
-                        float t = f * dot3(e2, q);
-                        // t = +inf passes "t > EPSILON" but never the reference's "t < closest.t"
-                        if (t > EPSILON && t < inf) {
-                            hit = true;
-                            key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)__float_as_uint(q2.w);
-                            hu = u;
-                            hv = v;
-                            ht = t;
-                        }
-                    }
-                }
+            float t, u, v;
+            // t = +inf passes "t > EPSILON" but never the reference's "t < closest.t"
+            if (tri_test(ro, rd, p0, e1, e2, t, u, v) && t < inf) {
+                hit = true;
+                key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)__float_as_uint(q2.w);
+                hu = u;
+                hv = v;
+                ht = t;
             }
         }
         if (hit)
@@ -1052,26 +767,12 @@ RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint3
                 } else { // no room: test it here
                     const float4 q0 = P.tri_pos[3 * slot], q1 = P.tri_pos[3 * slot + 1], q2 = P.tri_pos[3 * slot + 2];
                     const f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
-                    const float EPSILON = 1e-7f;
-                    f3 h = cross3(d, e2);
-                    float det = dot3(e1, h);
-                    if (!(det > -EPSILON && det < EPSILON)) {
-                        float f = 1.0f / det;
-                        f3 s = o - p0;
-                        float u = f * dot3(s, h);
-                        if (!(u < 0.0f || u > 1.0f)) {
-                            f3 q = cross3(s, e1);
-                            float v = f * dot3(d, q);
-                            if (!(v < 0.0f || u + v > 1.0f)) {
-                                float t = f * dot3(e2, q);
-                                const uint32_t pos = __float_as_uint(q2.w);
-                                if (t > EPSILON && (t < best.t || (t == best.t && pos < bpos)) && t < inf) {
-                                    best = Best{t, u, v, slot};
-                                    bpos = pos;
-                                    bm = m;
-                                }
-                            }
-                        }
+                    float t, u, v;
+                    const uint32_t pos = __float_as_uint(q2.w);
+                    if (tri_test(o, d, p0, e1, e2, t, u, v) && (t < best.t || (t == best.t && pos < bpos)) && t < inf) {
+                        best = Best{t, u, v, slot};
+                        bpos = pos;
+                        bm = m;
                     }
                 }
             } else if (OLD && k == KIND_SPHERE) {
@@ -1082,24 +783,12 @@ RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint3
                     J.jobs[j] = make_uint2((lane << kJobSlotBits) | kJobSphere | slot, __float_as_uint(fmaxf(tmin, 0.0f)));
                 } else { // no room: test it here
                     const float4 s0 = P.spheres[2 * slot], s1 = P.spheres[2 * slot + 1];
-                    f3 oc = mk3(s0.x, s0.y, s0.z) - o;
-                    float qa = dot3(d, d);
-                    float qb = -2.0f * dot3(d, oc);
-                    float qc = dot3(oc, oc) - s0.w * s0.w;
-                    float disc = qb * qb - 4 * qa * qc;
-                    if (!(disc < 0)) {
-                        float t = (-qb - sqrtf(disc)) / (2.0f * qa);
-                        bool ok = !(t < 0);
-                        if (!ok && __float_as_uint(s1.z) != 0u) {
-                            t = (-qb + sqrtf(disc)) / (2.0f * qa);
-                            ok = !(t < 0);
-                        }
-                        const uint32_t pos = __float_as_uint(s1.w);
-                        if (ok && (t < best.t || (t == best.t && pos < bpos)) && t < inf) {
-                            best = Best{t, 0.0f, 0.0f, kSphereBit | slot};
-                            bpos = pos;
-                            bm = fmaxf(tmin, 0.0f);
-                        }
+                    float t;
+                    const uint32_t pos = __float_as_uint(s1.w);
+                    if (sphere_test(o, d, s0, __float_as_uint(s1.z) != 0u, t) && (t < best.t || (t == best.t && pos < bpos)) && t < inf) {
+                        best = Best{t, 0.0f, 0.0f, kSphereBit | slot};
+                        bpos = pos;
+                        bm = fmaxf(tmin, 0.0f);
                     }
                 }
             } else if (OLD && k == KIND_MESH) { // the mesh's inner hierarchy follows inline, up to `skip`

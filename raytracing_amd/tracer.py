@@ -9,6 +9,7 @@ EST_SD_LOOP, EST_OLD_RECURSIVE = 0, 1
 TRAV_AUTO, TRAV_LANE, TRAV_WAVE, TRAV_NESTED, TRAV_FAST, TRAV_FAST_REPLAY, TRAV_REFERENCE, TRAV_FAST_REFILL, TRAV_BRUTE, TRAV_FAST_QUEUED, TRAV_FAST_INLINE, TRAV_FAST_SLICED = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 MISS = 0xFFFFFFFF
 SPLIT_TILE, SPLIT_SAMPLE = 0, 1
+CAMERA_AUTO, CAMERA_SEPARATE, CAMERA_FUSED = 0, 1, 2
 
 _STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_HIP", -4: "RT_ERR_NO_SCENE",
            -5: "RT_ERR_BAD_SCENE", -6: "RT_ERR_OUT_OF_MEMORY"}
@@ -99,9 +100,9 @@ class Tracer:
         self._check(N.hip().rt_set_camera(self._ctx, C.byref(c)))
 
     def set_options(self, bounce_limit=4, estimator=EST_SD_LOOP, seed=1, jitter=0.001, tile_rank=0, tile_world=1,
-                    collect_stats=False, sample_offset=0, traversal=0, multi_split=0):
+                    collect_stats=False, sample_offset=0, traversal=0, multi_split=0, camera_stage=0):
         o = N.OptionsC(bounce_limit, estimator, seed, jitter, tile_rank, tile_world, 1 if collect_stats else 0,
-                       sample_offset, traversal, multi_split)
+                       sample_offset, traversal, multi_split, camera_stage)
         self._check(N.hip().rt_set_options(self._ctx, C.byref(o)))
 
     def reset(self):

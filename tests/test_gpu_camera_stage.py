@@ -1,0 +1,102 @@
+"""The camera stage (RT_CAMERA_SEPARATE: camera rays and the walk's first slab test in a kernel of their own, sky samples
+folded without ever being queued) against the fused first launch (RT_CAMERA_FUSED) and the oracle: same bits -- images,
+primary ids, ray and test counts -- for every fast walk, on flat and pointer scenes, whole frames and tile shares, one call
+and the progressive protocol, ragged frames, bounce limits 0 and 1."""
+import numpy as np
+import pytest
+
+from helpers import O, R, WL, bits, objparse, oracle_camera, oracle_old_scene, oracle_sd_scene, product_old_scene, product_sd_scene
+
+pytestmark = pytest.mark.gpu
+
+FAST = [R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE, R.TRAV_FAST_SLICED]
+# the dragon fills the frame of its own camera; from further away most camera rays miss its root box
+FAR_CAMERA = R.Camera(1.0, (0.0, 0.10, 0.9), 2.0, 16.0 / 9.0, (-0.006, 0.073, -0.014))
+
+
+@pytest.fixture(scope="module")
+def tracer():
+    t = R.Tracer(0)
+    yield t
+    t.close()
+
+
+@pytest.fixture(scope="module")
+def dragon():
+    return product_sd_scene([WL.DRAGON_2426]), oracle_sd_scene([WL.DRAGON_2426])
+
+
+@pytest.mark.parametrize("trav", FAST)
+def test_flat_scene_both_stages_equal_the_oracle(tracer, dragon, trav):
+    ps, os_ = dragon
+    tracer.upload(ps)
+    for cam, (w, h) in ((FAR_CAMERA, (331, 187)), (WL.DRAGON_2426_CAMERA, (200, 112))):
+        tracer.set_camera(cam)
+        opt = O.make_options(bounce_limit=8, seed=7, trig=O.TRIG_POLY)
+        oimg, oprim, ost = os_.render(oracle_camera(cam), opt, w, h, 1, 5, want_primary=True)
+        res = {}
+        for stage in (R.CAMERA_SEPARATE, R.CAMERA_FUSED, R.CAMERA_AUTO):
+            tracer.set_options(bounce_limit=8, seed=7, collect_stats=True, traversal=trav, camera_stage=stage)
+            img, prim, st = tracer.trace(w, h, 1, 5, want_primary=True)
+            assert np.array_equal(prim, oprim), stage
+            assert np.array_equal(bits(img), bits(oimg)), stage
+            assert (st.rays, st.tri_hits) == (ost.rays, ost.tri_hits), stage
+            res[stage] = st
+        a, b = res[R.CAMERA_SEPARATE], res[R.CAMERA_FUSED]
+        assert (a.box_tests, a.tri_tests, a.replays) == (b.box_tests, b.tri_tests, b.replays)
+
+
+def test_tile_shares_and_progressive_calls(tracer, dragon):
+    ps, _ = dragon
+    tracer.upload(ps)
+    tracer.set_camera(FAR_CAMERA)
+    tracer.set_options(bounce_limit=4, seed=5, camera_stage=R.CAMERA_FUSED)
+    whole, wprim, st = tracer.trace(250, 141, 1, 70, want_primary=True)   # 70 samples: two chunks (64 + 6)
+    acc, rays = np.zeros_like(whole), 0
+    for r in range(3):
+        tracer.set_options(bounce_limit=4, seed=5, tile_rank=r, tile_world=3, camera_stage=R.CAMERA_SEPARATE)
+        part, _, s = tracer.trace(250, 141, 1, 70)
+        assert np.all((acc == 0) | (part == 0))
+        acc += part
+        rays += s.rays
+    assert rays == st.rays and np.array_equal(bits(whole), bits(acc))
+    tracer.set_options(bounce_limit=4, seed=5, camera_stage=R.CAMERA_SEPARATE)
+    for first, n in ((1, 1), (2, 3), (5, 64), (69, 2)):
+        part, pprim, _ = tracer.trace(250, 141, first, n, want_primary=(first == 1))
+        if first == 1:
+            assert np.array_equal(pprim, wprim)
+    assert np.array_equal(bits(whole), bits(part))
+
+
+@pytest.mark.parametrize("bounce", [0, 1, 2])
+def test_bounce_limits(tracer, dragon, bounce):
+    ps, os_ = dragon
+    tracer.upload(ps)
+    tracer.set_camera(FAR_CAMERA)
+    oimg, oprim, ost = os_.render(oracle_camera(FAR_CAMERA), O.make_options(bounce_limit=bounce, seed=2, trig=O.TRIG_POLY), 96, 54, 1, 3,
+                                  want_primary=True)
+    for stage in (R.CAMERA_SEPARATE, R.CAMERA_FUSED):
+        tracer.set_options(bounce_limit=bounce, seed=2, collect_stats=True, camera_stage=stage)
+        img, prim, st = tracer.trace(96, 54, 1, 3, want_primary=True)
+        assert np.array_equal(prim, oprim) and np.array_equal(bits(img), bits(oimg)) and st.rays == ost.rays
+
+
+@pytest.mark.parametrize("trav", [R.TRAV_FAST, R.TRAV_FAST_REFILL, R.TRAV_FAST_INLINE, R.TRAV_FAST_SLICED])
+def test_pointer_scene(tracer, trav):
+    tris, _ = objparse.load_obj(WL.CYLINDER)
+    spheres = WL.small_sphere_scene()[1:]          # without the ground sphere the scene covers part of the frame only
+    meshes = [(tris, R.MAT_LAMBERTIAN, (0.8, 0.3, 0.3, 1.0), 0.0)]
+    ps, os_ = product_old_scene(spheres, meshes), oracle_old_scene(spheres, meshes)
+    cam = R.Camera(3.19, (13.0, 2.0, 3.0), 2.0, 16.0 / 9.0, (0.0, 0.5, 0.0))
+    tracer.upload(ps)
+    tracer.set_camera(cam)
+    opt = O.make_options(bounce_limit=8, seed=3, trig=O.TRIG_POLY, accum=O.ACCUM_FORWARD)
+    oimg, oprim, ost = os_.render(oracle_camera(cam), opt, 200, 113, 1, 4, want_primary=True)
+    assert 0.02 < (oprim != R.MISS).mean() < 0.9
+    for stage in (R.CAMERA_SEPARATE, R.CAMERA_FUSED):
+        tracer.set_options(bounce_limit=8, estimator=R.EST_OLD_RECURSIVE, seed=3, collect_stats=True, traversal=trav,
+                           camera_stage=stage)
+        img, prim, st = tracer.trace(200, 113, 1, 4, want_primary=True)
+        assert np.array_equal(prim, oprim), stage
+        assert np.array_equal(bits(img), bits(oimg)), stage
+        assert (st.rays, st.sph_tests > 0) == (ost.rays, True)

@@ -114,7 +114,31 @@ def test_c_abi_exports_every_declared_symbol():
         assert lib.rt_create_multi(C.byref(ctx), ids, 2) == -2 and not ctx.value
     assert C.sizeof(N.Node) == 36 and C.sizeof(N.Tri) == 100          # == sizeof(sd::Node), sizeof(sd::Triangle)
     assert N.Node.flags.offset == 32 and N.Tri.mat.offset == 96
-    assert C.sizeof(N.CameraC) == 40 and C.sizeof(N.OptionsC) == 40 and C.sizeof(N.StatsC) == 64
+    assert C.sizeof(N.CameraC) == 40 and C.sizeof(N.OptionsC) == 44 and C.sizeof(N.StatsC) == 64
+
+
+def test_kernel_vector_helpers_equal_the_oracles_bit_for_bit():
+    """The kernels' fp32 helpers (host-evaluated through rt_vec_op: same source as the device code) against the oracle's, on
+    random inputs and on the inputs where another association would change the bits (tests/test_oracle_kats.py pins the
+    oracle's order itself)."""
+    lib = N.hip()
+    fp = C.POINTER(C.c_float)
+
+    def mine(op, *vecs):
+        arrs = [np.ascontiguousarray(x, dtype=np.float32) if x is not None else None for x in vecs] + [None] * (4 - len(vecs))
+        out = np.zeros(3, dtype=np.float32)
+        lib.rt_vec_op(op, *[x.ctypes.data_as(fp) if x is not None else None for x in arrs], out.ctypes.data_as(fp))
+        return out
+    rng = np.random.default_rng(11)
+    special = [np.array([1.0, 1e8, -1e8], np.float32), np.array([1e8, 1.0, -1e8], np.float32), np.array([1.0, 1.0, 1.0], np.float32),
+               np.array([1.0 + 2.0 ** -12, 1.0, 0.0], np.float32), np.array([1.0 + 2.0 ** -12, -1.0, 0.0], np.float32)]
+    vecs = special + [rng.normal(size=3).astype(np.float32) * np.float32(10.0 ** rng.integers(-3, 4)) for _ in range(300)]
+    for i in range(len(vecs) - 3):
+        a, b, c, v = vecs[i], vecs[i + 1], vecs[i + 2], vecs[i + 3]
+        assert bits(mine(0, a, b))[0] == bits(np.array([O.vec_op(O.VEC_DOT, a, b)], np.float32))[0]
+        assert np.array_equal(bits(mine(1, a, b)), bits(O.vec_op(O.VEC_CROSS, a, b)))
+        assert np.array_equal(bits(mine(2, a)), bits(O.vec_op(O.VEC_NORMALIZE, a)))
+        assert np.array_equal(bits(mine(3, a, b, c, v)), bits(O.vec_op(O.VEC_MAT3_MUL, a, b, c, v)))
 
 
 def test_kernels_are_compiled_for_gfx950(tmp_path):

@@ -145,8 +145,66 @@ def test_layout_matches_reference_dump():
     assert (n, root) == (3, ref["root"])
     dump = np.array(ref["nodes"], dtype=np.float32)
     assert np.array_equal(bits(fn[:, [0, 1, 8]]), bits(dump[:, [0, 1, 8]]))   # child indices and flags, bit-punned
-    assert np.allclose(fn[:, 2:8], dump[:, 2:8], atol=2e-5)                  # boxes (dump used a 1e-6 bias, 6 digits)
     assert np.allclose(ft, t, atol=1e-6)
+    # Boxes.  The dump was made when the leaf-box bias was 1e-6 and prints six significant digits.  The rule --
+    # pMin = min(vertices) - bias, pMax = max(vertices) + bias in fp32 (SimplifiedData.cpp:309-320), the two-leaf parent the
+    # plain min / max of its children (:339-341) -- restated here with that bias reproduces every printed digit of the dump,
+    # and with today's 1e-5 it reproduces the oracle's boxes bit for bit; so the oracle's boxes are the reference's rule.
+    def boxes(bias):
+        v = t[:, :24].reshape(2, 3, 8)[:, :, :3]
+        lo = (v.min(axis=1) - np.float32(bias)).astype(np.float32)
+        hi = (v.max(axis=1) + np.float32(bias)).astype(np.float32)
+        leaves = np.concatenate([lo, hi], axis=1)
+        root = np.concatenate([np.minimum(lo[0], lo[1]), np.maximum(hi[0], hi[1])])
+        return np.vstack([leaves, root]).astype(np.float32)
+
+    def six(a):
+        return [[float("%.6g" % x) for x in row] for row in np.asarray(a, dtype=np.float64)]
+    assert six(boxes(1e-6)) == six(dump[:, 2:8])
+    assert np.array_equal(bits(boxes(1e-5)), bits(fn[:, 2:8]))
+
+
+def test_vector_helpers_keep_glm_operation_order():
+    """glm's scalar definitions, which the reference's arithmetic goes through: dot = (x*x' + y*y') + z*z', cross by
+    components, normalize = v * (1 / sqrt(dot)), mat3 * v row by row as (m0*x + m1*y) + m2*z, min(a, b) = b < a ? b : a.
+    Inputs are chosen so that any other association or a fused multiply-add changes the bits."""
+    f = np.float32
+    a, b = np.array([1e8, 1.0, -1e8], f), np.array([1.0, 1.0, 1.0], f)
+    assert O.vec_op(O.VEC_DOT, a, b) == f(f(f(1e8) + f(1.0)) + f(-1e8)) == f(0.0)       # x + (y + z) would give 0 too ...
+    a2 = np.array([1.0, 1e8, -1e8], f)
+    assert O.vec_op(O.VEC_DOT, a2, b) == f(f(f(1.0) + f(1e8)) + f(-1e8)) == f(0.0)       # ... here x + (y + z) gives 1
+    assert f(f(1.0) + f(f(1e8) + f(-1e8))) == f(1.0)
+    # products are rounded before they are added: with a fused multiply-add the first product would enter unrounded
+    p, q = np.array([1.0 + 2.0 ** -12, 1.0, 0.0], f), np.array([1.0 + 2.0 ** -12, -1.0, 0.0], f)
+    prod = f(p[0] * q[0])
+    assert O.vec_op(O.VEC_DOT, p, q) == f(f(prod + f(-1.0)) + f(0.0))
+    assert float(O.vec_op(O.VEC_DOT, p, q)) != float(np.float64(p[0]) * np.float64(q[0]) - 1.0)
+    # cross(a, b) = (a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y)
+    u, v = np.array([1.1, 2.3, -0.7], f), np.array([-0.3, 0.9, 1.7], f)
+    want = np.array([f(f(u[1] * v[2]) - f(v[1] * u[2])), f(f(u[2] * v[0]) - f(v[2] * u[0])), f(f(u[0] * v[1]) - f(v[0] * u[1]))], f)
+    assert np.array_equal(bits(O.vec_op(O.VEC_CROSS, u, v)), bits(want))
+    # normalize multiplies by the rounded reciprocal of the rounded square root; it does not divide by the length
+    w = np.array([0.3, -0.7, 0.2], f)
+    d = f(f(f(w[0] * w[0]) + f(w[1] * w[1])) + f(w[2] * w[2]))
+    inv = f(f(1.0) / f(np.sqrt(d)))
+    assert np.array_equal(bits(O.vec_op(O.VEC_NORMALIZE, w)), bits(np.array([f(w[0] * inv), f(w[1] * inv), f(w[2] * inv)], f)))
+    many = np.random.default_rng(5).normal(size=(2000, 3)).astype(f)
+    differs = 0
+    for r in many:
+        dd = f(f(f(r[0] * r[0]) + f(r[1] * r[1])) + f(r[2] * r[2]))
+        differs += not np.array_equal(O.vec_op(O.VEC_NORMALIZE, r), (r / f(np.sqrt(dd))).astype(f))
+    assert differs > 100            # the two forms do differ in the last bit often enough to tell them apart
+    # mat3(c0, c1, c2) * v, per row (c0.r*v.x + c1.r*v.y) + c2.r*v.z
+    c0, c1, c2, x = np.array([1.0, 0.5, 1e8], f), np.array([1e8, 0.25, 1.0], f), np.array([-1e8, 3.0, -1e8], f), np.array([1.0, 1.0, 1.0], f)
+    row = lambda r: f(f(f(c0[r] * x[0]) + f(c1[r] * x[1])) + f(c2[r] * x[2]))
+    got = O.vec_op(O.VEC_MAT3_MUL, c0, c1, c2, x)
+    assert np.array_equal(bits(got), bits(np.array([row(0), row(1), row(2)], f))) and got[0] == 0.0 and got[2] == 0.0
+    # glm::min / glm::max with a NaN: min(a, b) = (b < a) ? b : a keeps a when b is NaN and takes ... a when a is NaN too
+    nan = f(np.nan)
+    m = O.vec_op(O.VEC_MIN, np.array([1.0, nan, 2.0], f), np.array([nan, 1.0, 1.0], f))
+    assert m[0] == 1.0 and np.isnan(m[1]) and m[2] == 1.0
+    m = O.vec_op(O.VEC_MAX, np.array([1.0, nan, 2.0], f), np.array([nan, 1.0, 3.0], f))
+    assert m[0] == 1.0 and np.isnan(m[1]) and m[2] == 3.0
 
 
 # ---- sphere, Objects.hpp:43-72 -------------------------------------------------------------------------

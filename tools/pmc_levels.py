@@ -9,7 +9,7 @@ table = {}  # dispatch order -> {counter: value}
 names = {}
 for path in sorted(glob.glob(sys.argv[1] + "/*/*/*_counter_collection.csv")):
     with open(path) as fh:
-        rows = [r for r in csv.DictReader(fh) if any(k in r["Kernel_Name"] for k in ("k_trace", "k_path", "k_refill", "k_sliced", "k_fold"))]
+        rows = [r for r in csv.DictReader(fh) if any(k in r["Kernel_Name"] for k in ("k_trace", "k_path", "k_refill", "k_sliced", "k_fold", "k_block", "k_camera"))]
     ids = sorted({int(r["Dispatch_Id"]) for r in rows})
     rank = {d: i for i, d in enumerate(ids)}
     for r in rows:

@@ -18,6 +18,7 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--stats", action="store_true")
 ap.add_argument("--bounce", type=int, default=0)
 ap.add_argument("--trav", type=int, default=0)
+ap.add_argument("--camera", type=int, default=0, help="RT_CAMERA_*: 0 auto, 1 separate camera stage, 2 fused")
 ap.add_argument("--image", action="store_true", help="also copy the mean image to the host (PCIe-inclusive total_ms)")
 a = ap.parse_args()
 wl = WL.make_workload(a.workload)
@@ -26,7 +27,7 @@ t = R.Tracer(0)
 t.upload(wl.scene)
 t.set_camera(wl.camera)
 t.set_options(bounce_limit=a.bounce or wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
-              collect_stats=a.stats, traversal=a.trav)
+              collect_stats=a.stats, traversal=a.trav, camera_stage=a.camera)
 for i in range(a.reps):
     _, _, st = t.trace(W, H, 1, spp, want_image=a.image)
     print(f"{a.workload} {W}x{H} spp={spp} rep={i}: rays={st.rays} kernel_ms={st.kernel_ms:.3f} "
