@@ -508,9 +508,10 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
         P.sub_in = ws.levels;
         P.sub_cursor = ws.levels + 1;
         P.sub_out = ws.levels + (size_t)kSubQueues * 32;
-        uint32_t blocks = pl.full_grid;
-        if (blocks > (P.n_my_tiles + 3) / 4)
-            blocks = (P.n_my_tiles + 3) / 4;
+        // one tile per wave: the tiles cost the same, and waves that start as others finish keep the chip full to the end
+        uint32_t blocks = (P.n_my_tiles + 3) / 4;
+        if (blocks > 16u * pl.full_grid)
+            blocks = 16u * pl.full_grid;
         if (blocks < 1)
             blocks = 1;
         dim3 grid(blocks);

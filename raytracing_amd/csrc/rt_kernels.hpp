@@ -167,8 +167,7 @@ RT_D float4 sky_sample(const f3 d) {
 
 // The slab test of the fast walk (closest = +inf) against the root record of the fast tree: does the walk of this ray
 // get past its first record at all?
-RT_D bool meets_root_box(const KParams &P, const f3 o, const f3 inv) {
-    const float4 a = P.fnodes[0], b = P.fnodes[1];
+RT_D bool meets_root_box(const float4 a, const float4 b, const f3 o, const f3 inv) {
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     const float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
     const float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
@@ -281,6 +280,20 @@ __global__ void __launch_bounds__(256) k_trace(const KParams P) {
     }
 }
 
+// What k_camera queues for a camera ray that got past the root box: 16 bytes -- direction and colour slot -- packed
+// densely at the start of its sub-queue's region (record i of sub-queue q at float4 index REC4 * q * sub_cap + i).  The
+// rest of the path state of a camera ray is known: origin, unit throughput, depth 0, and the RNG key of (pixel, sample).
+RT_D void read_camera_record(const KParams &P, const float4 r, Path &path, uint32_t &cidx) {
+    cidx = __float_as_uint(r.w);
+    const uint32_t s = cidx / P.npix, pixel = cidx - s * P.npix;
+    path.o = P.cam_pos;
+    path.d = mk3(r.x, r.y, r.z);
+    path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
+    path.rr = 1.0f;
+    path.depth = 0;
+    path.key = pcg(pcg(P.seed_hash + pixel) + (uint32_t)(P.chunk_first + (int)s) + P.sample_offset);
+}
+
 // Wavefront path kernel: one launch per bounce level.
 //
 // Level 0 generates the camera rays of `S` consecutive samples of every pixel this context owns.  A
@@ -375,7 +388,9 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : (WALK == WALK_QUE
             path.rr = 1.0f;
             path.depth = 0;
             path.key = 0;
-            if (live) {
+            if (live && P.camera_stage != 0 && P.level == 1) {
+                read_camera_record(P, P.q_in[4 * ((size_t)my_q * P.sub_cap) + (g - my_q * P.sub_cap)], path, cidx);
+            } else if (live) {
                 const float4 r0 = P.q_in[4 * (size_t)g], r1 = P.q_in[4 * (size_t)g + 1], r2 = P.q_in[4 * (size_t)g + 2],
                              r3 = P.q_in[4 * (size_t)g + 3];
                 path.o = mk3(r0.x, r0.y, r0.z);
@@ -566,14 +581,18 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
                     out_q = my_q;
                 } else if (cur_b * 64u + item < my_count) {
                     const size_t g = (size_t)my_q * P.sub_cap + (size_t)cur_b * 64u + item;
-                    const float4 r0 = P.q_in[4 * g], r1 = P.q_in[4 * g + 1], r2 = P.q_in[4 * g + 2], r3 = P.q_in[4 * g + 3];
-                    path.o = mk3(r0.x, r0.y, r0.z);
-                    path.d = mk3(r0.w, r1.x, r1.y);
-                    path.thr = make_float4(r1.z, r1.w, r2.x, r2.y);
-                    path.rr = r2.z;
-                    path.key = __float_as_uint(r2.w);
-                    cidx = __float_as_uint(r3.x);
-                    path.depth = (int)__float_as_uint(r3.y);
+                    if (P.camera_stage != 0 && P.level == 1) {
+                        read_camera_record(P, P.q_in[4 * ((size_t)my_q * P.sub_cap) + ((size_t)cur_b * 64u + item)], path, cidx);
+                    } else {
+                        const float4 r0 = P.q_in[4 * g], r1 = P.q_in[4 * g + 1], r2 = P.q_in[4 * g + 2], r3 = P.q_in[4 * g + 3];
+                        path.o = mk3(r0.x, r0.y, r0.z);
+                        path.d = mk3(r0.w, r1.x, r1.y);
+                        path.thr = make_float4(r1.z, r1.w, r2.x, r2.y);
+                        path.rr = r2.z;
+                        path.key = __float_as_uint(r2.w);
+                        cidx = __float_as_uint(r3.x);
+                        path.depth = (int)__float_as_uint(r3.y);
+                    }
                     out_q = (my_q + cur_b) & (uint32_t)(kSubQueues - 1);
                     has = true;
                 }
@@ -753,7 +772,9 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
             path.rr = 1.0f;
             path.depth = 0;
             path.key = 0;
-            if (live) {
+            if (live && P.camera_stage != 0 && P.level == 1) { // a camera ray: its walk has not started
+                read_camera_record(P, P.q_in[6 * ((size_t)my_q * P.sub_cap) + local], path, cidx);
+            } else if (live) {
                 const size_t g = (size_t)my_q * P.sub_cap + local;
                 const float4 r0 = P.q_in[6 * g], r1 = P.q_in[6 * g + 1], r2 = P.q_in[6 * g + 2], r3 = P.q_in[6 * g + 3],
                              r4 = P.q_in[6 * g + 4], r5 = P.q_in[6 * g + 5];
@@ -861,7 +882,7 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
 // sky.  Giving each of them a queue slot, a colour slot and a lane of the path kernel costs more than the ray: 32 bytes of
 // HBM traffic per sample, and the wave's walk machinery for one record.  Here a wave takes an 8x8 tile and each lane runs
 // through the chunk's S samples of its pixel: camera ray, root slab test.  Only the samples that pass go to the queue (as
-// walks that have not started; the path kernels take them from level 1 on); the others are noted as a clear bit in the
+// 16-byte records, see read_camera_record; the path kernels take them from level 1 on); the others are noted as a clear bit in the
 // pixel's `deferred` word and never touch memory again: k_fold regenerates their ray and folds the sky colour where their
 // turn in the sample order comes.  One queue reservation per tile (none for a tile that is all sky); records are
 // sample-major within it, so a batch of the next level holds neighbouring pixels of one sample.
@@ -872,6 +893,7 @@ __global__ void __launch_bounds__(256) k_camera(const KParams P) {
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     unsigned long long n_sky = 0ull;
+    const float4 root_a = P.fnodes[0], root_b = P.fnodes[1]; // the root record's box, once
     for (uint32_t j = wave_id; j < P.n_my_tiles; j += n_waves) {
         const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
         const uint32_t tile_y = fastdiv(tile, P.div_tiles_x);
@@ -886,7 +908,7 @@ __global__ void __launch_bounds__(256) k_camera(const KParams P) {
                 f3 d;
                 camera_ray(P, x, y, pixel, P.chunk_first + s, key, d);
                 const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
-                if (meets_root_box(P, P.cam_pos, inv))
+                if (meets_root_box(root_a, root_b, P.cam_pos, inv))
                     mask |= 1ull << s;
             }
             P.deferred[pixel] = mask;
@@ -921,18 +943,9 @@ __global__ void __launch_bounds__(256) k_camera(const KParams P) {
                 uint32_t key;
                 f3 d;
                 camera_ray(P, x, y, pixel, P.chunk_first + s, key, d);
-                const size_t slot = (size_t)q * P.sub_cap + (size_t)base + (size_t)__builtin_popcountll(bm & below);
+                const size_t slot = (size_t)base + (size_t)__builtin_popcountll(bm & below);
                 const uint32_t cidx = (uint32_t)s * P.npix + pixel;
-                P.q_out[REC4 * slot] = make_float4(P.cam_pos.x, P.cam_pos.y, P.cam_pos.z, d.x);
-                P.q_out[REC4 * slot + 1] = make_float4(d.y, d.z, 1.f, 1.f);
-                P.q_out[REC4 * slot + 2] = make_float4(1.f, 1.f, 1.0f, __uint_as_float(key));
-                if (REC4 == 4) {
-                    P.q_out[REC4 * slot + 3] = make_float4(__uint_as_float(cidx), __uint_as_float(0u), 0.f, 0.f);
-                } else { // a walk that has not started: Walk{0, kNone, kNone, 0}, no candidate yet
-                    P.q_out[REC4 * slot + 3] = make_float4(__uint_as_float(cidx), __uint_as_float(0u), __uint_as_float(0u), __uint_as_float(kNone));
-                    P.q_out[REC4 * slot + 4] = make_float4(__builtin_inff(), 0.0f, 0.0f, __uint_as_float(kNone));
-                    P.q_out[REC4 * slot + 5] = make_float4(0.0f, __uint_as_float(kNone), 0.0f, __uint_as_float(kNone));
-                }
+                P.q_out[REC4 * ((size_t)q * P.sub_cap) + slot] = make_float4(d.x, d.y, d.z, __uint_as_float(cidx));
             }
             base += (unsigned int)__builtin_popcountll(bm);
         }

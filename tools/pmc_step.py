@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Whole-step figures from the counter passes of ONE trace call (tools/pmc_step.sh): HBM bytes, VALU issue utilisation,
+active lanes per VALU instruction, summed over every kernel of the call.  Prints one JSON object.
+usage: pmc_step.py <pmc dir> <source label>"""
+import csv
+import glob
+import json
+import sys
+
+KERNELS = ("k_trace", "k_path", "k_refill", "k_sliced", "k_fold", "k_camera")
+tot = {}
+for path in sorted(glob.glob(sys.argv[1] + "/*/*/*_counter_collection.csv")):
+    with open(path) as fh:
+        seen = set()
+        for r in csv.DictReader(fh):
+            if not any(k in r["Kernel_Name"] for k in KERNELS):
+                continue
+            name = r["Counter_Name"]
+            if (path, name) not in seen and name in tot and name in ("SQ_INSTS_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE"):
+                continue  # collected in more than one pass: keep the first pass's
+            tot[name] = tot.get(name, 0.0) + float(r["Counter_Value"])
+            seen.add((path, name))
+cycles = tot["GRBM_GUI_ACTIVE"] / 8.0          # the counter is summed over the 8 XCDs
+simds = 256 * 4
+out = {
+    # memory-side reads are tallied at 64 B per 128-B request on gfx950: doubled; writes as counted (both in KB)
+    "hbm_bytes_per_step": int((2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0),
+    "hbm_read_bytes_per_step": int(2.0 * tot["FETCH_SIZE"] * 1024.0),
+    "hbm_write_bytes_per_step": int(tot["WRITE_SIZE"] * 1024.0),
+    # a VALU instruction occupies its SIMD's issue for 4 cycles; kernels of one call run one after the other
+    "valu_issue_utilisation": tot["SQ_INSTS_VALU"] * 4.0 / (simds * cycles),
+    "active_lanes": tot["SQ_THREAD_CYCLES_VALU"] / tot["SQ_INSTS_VALU"],
+    "valu_instructions_per_step": tot["SQ_INSTS_VALU"],
+    "vmem_read_instructions_per_step": tot.get("SQ_INSTS_VMEM_RD"),
+    "ta_busy": tot["TA_TA_BUSY_sum"] / 256.0 / cycles if "TA_TA_BUSY_sum" in tot else None,
+    "gpu_cycles_under_counters": cycles,
+    "source": sys.argv[2] if len(sys.argv) > 2 else None,
+}
+print(json.dumps(out))
