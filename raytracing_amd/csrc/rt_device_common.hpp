@@ -29,6 +29,7 @@ constexpr int kCounterSlots = 64, kCounterStride = 16; // statistics are added i
 constexpr int kMaxLevels = 64;             // bounce levels a wavefront trace can launch (bounce_limit <= 62)
 constexpr uint32_t kTailRays = 256u << 10;  // a level with no more rays than this follows every path to its end in one launch
 constexpr uint32_t kSlice = 128;            // k_sliced: records a ray is taken further per round
+constexpr int kSliceBurst = 32;            // k_sliced: records between two looks at the wave's list of noted tests
 constexpr int kSliceExtraRounds = 2;       // k_sliced: launches beyond one per bounce level (the last one finishes whatever is left)
 constexpr int kChunkSamples = 64;          // samples per pixel traced per wavefront chunk
 constexpr size_t kMaxItems = 192u << 20;   // work items (pixel samples) per chunk: bounds the queue workspace

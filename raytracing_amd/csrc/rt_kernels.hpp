@@ -805,19 +805,33 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
                 path.inv = mk3(1.0f / path.d.x, 1.0f / path.d.y, 1.0f / path.d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
                 if (w.idx == 0u)
                     cnt.rays++; // a walk starts at record 0 and never returns to it
-                fast_walk_from<OLD, STATS, -1>(P, path.o, path.d, path.inv, w, cnt, [&](const Cand &c) {
-                    if ((c.t < best.t || (c.t == best.t && c.pos < bpos)) && c.t < __builtin_inff()) {
-                        best = Best{c.t, c.u, c.v, c.ref};
-                        bpos = c.pos;
-                        bm = fmaxf(c.m, c.mesh_m);
-                    }
-                }, [&](const uint32_t sphere, const uint32_t slot, const float m) -> bool {
-                    const uint32_t j = atomicAdd(&J.count, 1u);
-                    if (!(j < kJobCap && slot < kJobSphere))
-                        return false; // no room: the walk runs the test itself
-                    J.jobs[j] = make_uint2((lane << kJobSlotBits) | (sphere != 0u ? kJobSphere : 0u) | slot, __float_as_uint(m));
-                    return true;
-                });
+            }
+            // The slice is walked in bursts; between two bursts the wave runs the tests noted so far if its list is more than
+            // half full.  A full list makes the walk test on the spot, a few lanes at a time, which costs far more than a
+            // pass of resolve_jobs (the minima per owner stay in the wave's LDS words from one pass to the next).
+            for (int left = slice;;) {
+                if (live && w.idx < n) {
+                    w.slice = left < kSliceBurst ? left : kSliceBurst;
+                    fast_walk_from<OLD, STATS, -1>(P, path.o, path.d, path.inv, w, cnt, [&](const Cand &c) {
+                        if ((c.t < best.t || (c.t == best.t && c.pos < bpos)) && c.t < __builtin_inff()) {
+                            best = Best{c.t, c.u, c.v, c.ref};
+                            bpos = c.pos;
+                            bm = fmaxf(c.m, c.mesh_m);
+                        }
+                    }, [&](const uint32_t sphere, const uint32_t slot, const float m) -> bool {
+                        const uint32_t j = atomicAdd(&J.count, 1u);
+                        if (!(j < kJobCap && slot < kJobSphere))
+                            return false; // no room: the walk runs the test itself
+                        J.jobs[j] = make_uint2((lane << kJobSlotBits) | (sphere != 0u ? kJobSphere : 0u) | slot, __float_as_uint(m));
+                        return true;
+                    });
+                }
+                left = left > kSliceBurst ? left - kSliceBurst : 0;
+                __builtin_amdgcn_wave_barrier();
+                if (left == 0 || __ballot(live && w.idx < n) == 0ull)
+                    break;
+                if (J.count > kJobCap / 2u)
+                    resolve_jobs<OLD>(P, lane, path.o, path.d, J);
             }
             // the noted tests of this slice, then every lane's best is complete up to where its walk stands
             resolve_jobs<OLD>(P, lane, path.o, path.d, J);
