@@ -234,6 +234,20 @@ int rt_reset(rt_ctx *ctx);
 int rt_trace(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *out_rgba_mean,
              uint32_t *out_primary_id, rt_stats *stats);
 
+/* rt_trace without the wait, for callers that can have the next frame computed while they use this one -- the
+ * reference's frame loop asks for sample n+1 right after sample n unless the camera or the scene changed
+ * (TracerAsync::render, Renderer/TracerImpl.cpp:9-12; Renderer::render resets on RenderState::Dirty, Renderer.cpp:86-90).
+ * rt_trace_begin enqueues the samples and the copy of the resulting mean to out_rgba_mean (page-locked memory from
+ * rt_alloc_host lets the copy overlap the next call's kernels) and returns; at most two begun calls may be in flight.
+ * rt_trace_end waits for the oldest one: its image is in its out_rgba_mean, and the context's running mean is now the
+ * mean after that call.  A begun call continues from the mean of the call begun before it (or of the last ended call)
+ * and leaves the last ENDED call's mean untouched, so rt_trace_discard -- or any rt_trace, rt_reset, rt_upload_scene --
+ * drops what is in flight as if it had never been begun.  The bits are rt_trace's.  stats (may be NULL): counters as
+ * accumulated since the previous rt_sync / rt_trace, which may include part of a call begun later; no kernel times. */
+int rt_trace_begin(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *out_rgba_mean);
+int rt_trace_end(rt_ctx *ctx, rt_stats *stats);
+int rt_trace_discard(rt_ctx *ctx);
+
 /* Same work, asynchronous, into caller-owned DEVICE memory: d_rgba (W*H*4 floats, holds the running
  * mean before and after; the caller zeroes it for first_sample == 1) and d_primary_id (W*H, may be
  * NULL).  Enqueued on the context's stream; nothing is copied to the host. */

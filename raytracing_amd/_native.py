@@ -61,7 +61,7 @@ assert C.sizeof(Node) == 36 and C.sizeof(Tri) == 100 and C.sizeof(Sphere) == 24 
 HIP_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_set_options",
                "rt_reset", "rt_trace", "rt_trace_device", "rt_set_stream", "rt_sync", "rt_version", "rt_layout_scene",
                "rt_layout_free", "rt_set_pipelining", "rt_join", "rt_alloc_host", "rt_free_host", "rt_create_multi",
-               "rt_device_count", "rt_reserve", "rt_vec_op", "rt_trace_device_noalloc", "rt_noalloc_max_pixels"]
+               "rt_device_count", "rt_reserve", "rt_vec_op", "rt_trace_begin", "rt_trace_end", "rt_trace_discard", "rt_trace_device_noalloc", "rt_noalloc_max_pixels"]
 
 _hip = None
 _host = None
@@ -81,6 +81,9 @@ def hip():
         L.rt_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.rt_trace_device_noalloc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.rt_noalloc_max_pixels.restype = C.c_uint64
+        L.rt_trace_begin.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+        L.rt_trace_end.argtypes = [vp, C.POINTER(StatsC)]
+        L.rt_trace_discard.argtypes = [vp]
         L.rt_vec_op.argtypes = [C.c_int, fp, fp, fp, fp, fp]
         L.rt_vec_op.restype = None
         L.rt_destroy.argtypes = [vp]
@@ -150,6 +153,10 @@ def host():
         L.rth_old_publish.argtypes = [vp]
         L.rth_harness_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_uint32, C.c_float]
         L.rth_harness_create.restype = vp
+        L.rth_harness_create_devices.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_uint32, C.c_float]
+        L.rth_harness_create_devices.restype = vp
+        L.rth_harness_set_look_ahead.argtypes = [vp, C.c_int]
+        L.rth_harness_set_look_ahead.restype = None
         L.rth_harness_destroy.argtypes = [vp]
         L.rth_harness_destroy.restype = None
         for name in ("rth_harness_load", "rth_harness_render", "rth_harness_reset", "rth_harness_sample_count"):

@@ -153,8 +153,8 @@ int rth_old_publish(void *s) {
 
 // ---- plug-in harness: what Renderer::changeMode / Renderer::render do, without GL ----
 // mode 0 = HIP_SdScene, 1 = HIP_Scene
-void *rth_harness_create(int mode, int device, int width, int height, const float *cam10, int bounce_limit,
-                         uint32_t seed, float jitter) {
+static void *harness_create(int mode, const int *devices, int n_devices, int width, int height, const float *cam10,
+                            int bounce_limit, uint32_t seed, float jitter) {
     Harness *h = new Harness();
     int rc = guarded([&] {
         h->cam.focalLength = cam10[0];
@@ -164,13 +164,14 @@ void *rth_harness_create(int mode, int device, int width, int height, const floa
         h->cam.height = cam10[8];
         h->cam.aspectRatio = cam10[9];
         Trace::bounceLimit = bounce_limit;
+        const std::vector<int> devs(devices, devices + n_devices);
         if (mode == 0) {
-            SdSceneHIPContext c(h->cam, device);
+            SdSceneHIPContext c(h->cam, devs);
             c.seed = seed;
             c.perturbStrength = jitter;
             h->pipeline = std::make_unique<RenderPipeline<SdSceneHIPContext, LoadSdSceneHIP, TraceSdSceneHIP>>(std::move(c));
         } else {
-            SceneHIPContext c(h->cam, device);
+            SceneHIPContext c(h->cam, devs);
             c.seed = seed;
             c.perturbStrength = jitter;
             h->pipeline = std::make_unique<RenderPipeline<SceneHIPContext, LoadSceneHIP, TraceSceneHIP>>(std::move(c));
@@ -182,6 +183,23 @@ void *rth_harness_create(int mode, int device, int width, int height, const floa
         return nullptr;
     }
     return h;
+}
+void *rth_harness_create(int mode, int device, int width, int height, const float *cam10, int bounce_limit,
+                         uint32_t seed, float jitter) {
+    return harness_create(mode, &device, 1, width, height, cam10, bounce_limit, seed, jitter);
+}
+// the same render mode over several GPUs (rt_create_multi behind the one context)
+void *rth_harness_create_devices(int mode, const int *devices, int n_devices, int width, int height, const float *cam10,
+                                 int bounce_limit, uint32_t seed, float jitter) {
+    return harness_create(mode, devices, n_devices, width, height, cam10, bounce_limit, seed, jitter);
+}
+// look-ahead of the trace method on / off (on by default)
+void rth_harness_set_look_ahead(void *h, int on) {
+    ITraceMethod *m = ((Harness *)h)->pipeline->getTraceMethod();
+    if (auto *a = dynamic_cast<TraceSdSceneHIP *>(m))
+        a->lookAhead = on != 0;
+    if (auto *b = dynamic_cast<TraceSceneHIP *>(m))
+        b->lookAhead = on != 0;
 }
 void rth_harness_destroy(void *h) { delete (Harness *)h; }
 int rth_harness_load(void *h) { // uploader->upload(*pipeline->getLoadMethod()), Renderer.cpp:83

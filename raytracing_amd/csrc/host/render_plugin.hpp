@@ -12,6 +12,9 @@
 // reference's own headers; the adaptor classes compile against either.
 #pragma once
 
+#include <atomic>
+#include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -144,13 +147,23 @@ struct HIPContextBase {
     Camera &cam;
     uint32_t seed = 1;
     float perturbStrength = 0.001f; // Renderer/TraceMethods.cpp:48
+    std::atomic<uint64_t> sceneVersion{0}; // counts the loads: frames computed ahead of a load are of the old scene
 
     explicit HIPContextBase(Camera &c, int device = 0) : cam(c) {
         int rc = rt_create(&ctx, device);
         if (rc != RT_OK)
             throw std::runtime_error("rt_create failed (" + std::to_string(rc) + "): no usable HIP device");
     }
-    HIPContextBase(HIPContextBase &&o) noexcept : ctx(o.ctx), cam(o.cam), seed(o.seed), perturbStrength(o.perturbStrength) { o.ctx = nullptr; }
+    // several GPUs behind the one render mode (rt_create_multi): the frame is put together on devices[0]
+    HIPContextBase(Camera &c, const std::vector<int> &devices) : cam(c) {
+        int rc = rt_create_multi(&ctx, devices.data(), (int)devices.size());
+        if (rc != RT_OK)
+            throw std::runtime_error("rt_create_multi failed (" + std::to_string(rc) + "): no usable HIP device");
+    }
+    HIPContextBase(HIPContextBase &&o) noexcept
+        : ctx(o.ctx), cam(o.cam), seed(o.seed), perturbStrength(o.perturbStrength), sceneVersion(o.sceneVersion.load()) {
+        o.ctx = nullptr;
+    }
     HIPContextBase(const HIPContextBase &) = delete;
     ~HIPContextBase() {
         if (ctx)
@@ -183,6 +196,7 @@ class LoadSdSceneHIP : public ILoadMethod {
                                         ds.triangles.data(), (uint32_t)ds.triangles.size(), nullptr, 0, nullptr, 0,
                                         RT_ORDER_RIGHT_FIRST),
                         "LoadSdSceneHIP");
+        DIContext.sceneVersion++;
     }
 };
 // LoadSceneCPU::load (Renderer/LoadMethods.cpp:65-73) catches and logs; so does this one.
@@ -201,6 +215,7 @@ class LoadSceneHIP : public ILoadMethod {
                                             (uint32_t)s.spheres.size(), s.materials.data(), (uint32_t)s.materials.size(),
                                             RT_ORDER_LEFT_FIRST),
                             "LoadSceneHIP");
+            DIContext.sceneVersion++;
             lastError.clear();
         } catch (std::exception &e) {
             lastError = e.what();
@@ -213,30 +228,65 @@ class LoadSceneHIP : public ILoadMethod {
 // One call = one more sample per pixel folded into the running mean, then the image handed to the
 // output texture (Renderer/TraceMethods.cpp:45-80).  The running mean stays on the device between
 // calls; sampleCount == 1 restarts it.
+//
+// Look-ahead: the reference's frame loop asks for sample n+1 right after sample n unless something changed
+// (TracerAsync::render, Renderer/TracerImpl.cpp:9-12), so when a call returns sample n the samples n+1 and n+2 are
+// already in flight on the device (rt_trace_begin), their images on the way to page-locked staging buffers while the
+// application uploads and draws frame n.  The next call finds its frame ready if it asks for sample n+1 of the same
+// frame size with the same camera, options and scene; anything else (RenderState::Dirty -> resetSamples, a resize, a
+// load) drops what is in flight -- it never touched the running mean the application has seen -- and starts over.
 template <int ESTIMATOR, class Context> class TraceHIPImpl : public ITraceMethod {
     Context &DIContext;
-    // page-locked staging for the image on its way to Texture2D::setData (pageable memory if that cannot be had)
-    float *staging = nullptr;
+    static constexpr int kAhead = 2;          // calls kept in flight
+    float *staging[kAhead + 1] = {nullptr, nullptr, nullptr}; // page-locked (pageable memory if that cannot be had)
     size_t stagingFloats = 0;
     bool stagingPinned = false;
+    int nextStaging = 0;
+    struct Flight {
+        int sample;
+        unsigned width, height;
+        rt_camera cam;
+        rt_options opt;
+        uint64_t scene;
+        float *image;
+    };
+    std::deque<Flight> flights;
     void releaseStaging() {
-        if (staging && stagingPinned)
-            rt_free_host(staging);
-        else
-            delete[] staging;
-        staging = nullptr;
+        for (float *&p : staging) {
+            if (p && stagingPinned)
+                rt_free_host(p);
+            else
+                delete[] p;
+            p = nullptr;
+        }
         stagingFloats = 0;
+    }
+    void drop() {
+        if (!flights.empty())
+            (void)rt_trace_discard(DIContext.ctx);
+        flights.clear();
+    }
+    void begin(int sample, unsigned w, unsigned h, const rt_camera &cam, const rt_options &opt, uint64_t scene) {
+        float *image = staging[nextStaging];
+        nextStaging = (nextStaging + 1) % (kAhead + 1);
+        DIContext.check(rt_trace_begin(DIContext.ctx, (int)w, (int)h, sample, 1, image), "rt_trace_begin"); // RT_ERR_NO_SCENE carries
+        flights.push_back(Flight{sample, w, h, cam, opt, scene, image});                                   // "Scene is not loaded."
     }
 
   public:
     rt_stats lastStats{};
+    bool lookAhead = true;
     explicit TraceHIPImpl(Context &c) : DIContext(c) {}
-    ~TraceHIPImpl() override { releaseStaging(); }
+    ~TraceHIPImpl() override {
+        drop();
+        releaseStaging();
+    }
     TraceHIPImpl(const TraceHIPImpl &) = delete;
     TraceHIPImpl &operator=(const TraceHIPImpl &) = delete;
     void trace(const Texture2D &traceInput, Texture2D &traceOutput, int sampleCount) override {
         const Camera &c = DIContext.cam; // read live every call, the UI may have moved it
         rt_camera cam;
+        std::memset(&cam, 0, sizeof(cam));
         cam.focal_length = c.focalLength;
         for (int k = 0; k < 3; k++) {
             cam.position[k] = c.position[k];
@@ -245,8 +295,8 @@ template <int ESTIMATOR, class Context> class TraceHIPImpl : public ITraceMethod
         cam.width = c.width;
         cam.height = c.height;
         cam.aspect_ratio = c.aspectRatio;
-        DIContext.check(rt_set_camera(DIContext.ctx, &cam), "rt_set_camera");
-        rt_options opt{};
+        rt_options opt;
+        std::memset(&opt, 0, sizeof(opt));
         opt.bounce_limit = Trace::bounceLimit;
         opt.estimator = ESTIMATOR;
         opt.seed = DIContext.seed;
@@ -254,20 +304,60 @@ template <int ESTIMATOR, class Context> class TraceHIPImpl : public ITraceMethod
         opt.tile_rank = 0;
         opt.tile_world = 1;
         opt.traversal = (ESTIMATOR == RT_EST_OLD_RECURSIVE && !BVHSettings::toggleBVHAccel) ? RT_TRAV_BRUTE : RT_TRAV_AUTO;
-        DIContext.check(rt_set_options(DIContext.ctx, &opt), "rt_set_options");
-        const size_t need = (size_t)traceInput.Width * traceInput.Height * 4;
+        const unsigned w = traceInput.Width, h = traceInput.Height;
+        const uint64_t scene = DIContext.sceneVersion.load();
+        const size_t need = (size_t)w * h * 4;
         if (need != stagingFloats) {
+            drop();
             releaseStaging();
-            staging = (float *)rt_alloc_host(need * sizeof(float));
-            stagingPinned = staging != nullptr;
-            if (!staging)
-                staging = new float[need];
+            stagingPinned = true;
+            for (float *&p : staging) {
+                p = stagingPinned ? (float *)rt_alloc_host(need * sizeof(float)) : nullptr;
+                if (!p) {
+                    stagingPinned = false; // (buffers already handed out stay page-locked only if all are)
+                    break;
+                }
+            }
+            if (!stagingPinned) {
+                for (float *&p : staging)
+                    if (p) {
+                        rt_free_host(p);
+                        p = nullptr;
+                    }
+                for (float *&p : staging)
+                    p = new float[need];
+            }
             stagingFloats = need;
         }
-        DIContext.check(rt_trace(DIContext.ctx, (int)traceInput.Width, (int)traceInput.Height, sampleCount, 1, staging,
-                                 nullptr, &lastStats),
-                        "rt_trace"); // RT_ERR_NO_SCENE carries "Scene is not loaded." (TraceMethods.cpp:54-56)
-        traceOutput.setData(staging);
+        const bool single = rt_device_count(DIContext.ctx) == 1;
+        if (!single) { // several devices behind the context: synchronous calls
+            DIContext.check(rt_set_camera(DIContext.ctx, &cam), "rt_set_camera");
+            DIContext.check(rt_set_options(DIContext.ctx, &opt), "rt_set_options");
+            DIContext.check(rt_trace(DIContext.ctx, (int)w, (int)h, sampleCount, 1, staging[0], nullptr, &lastStats), "rt_trace");
+            traceOutput.setData(staging[0]);
+            return;
+        }
+        auto matches = [&](const Flight &f, int sample) {
+            return f.sample == sample && f.width == w && f.height == h && f.scene == scene &&
+                   std::memcmp(&f.cam, &cam, sizeof(cam)) == 0 && std::memcmp(&f.opt, &opt, sizeof(opt)) == 0;
+        };
+        if (!flights.empty() && !matches(flights.front(), sampleCount))
+            drop(); // not the frame that was computed ahead
+        DIContext.check(rt_set_camera(DIContext.ctx, &cam), "rt_set_camera");
+        DIContext.check(rt_set_options(DIContext.ctx, &opt), "rt_set_options");
+        if (flights.empty())
+            begin(sampleCount, w, h, cam, opt, scene);
+        if (rt_trace_end(DIContext.ctx, &lastStats) != RT_OK) {
+            // a load went in between (it drops what is in flight): this frame again, from the scene as it is now
+            flights.clear();
+            begin(sampleCount, w, h, cam, opt, DIContext.sceneVersion.load());
+            DIContext.check(rt_trace_end(DIContext.ctx, &lastStats), "rt_trace_end");
+        }
+        float *image = flights.front().image;
+        flights.pop_front();
+        while (lookAhead && (int)flights.size() < kAhead)
+            begin((flights.empty() ? sampleCount : flights.back().sample) + 1, w, h, cam, opt, scene);
+        traceOutput.setData(image);
     }
 };
 using TraceSdSceneHIP = TraceHIPImpl<RT_EST_SD_LOOP, SdSceneHIPContext>;

@@ -42,7 +42,8 @@ struct KParams {
     const float4 *tri_nrm; // 3 x float4 per triangle slot: n0, n1, n2
     const float4 *spheres; // 2 x float4 per sphere
     const float4 *mats;    // 2 x float4 per material
-    float4 *image;
+    float4 *image;          // the running mean the folds write ...
+    const float4 *image_in; // ... and the one the first fold of the call continues from (the same buffer unless look-ahead)
     uint32_t *primary;
     unsigned int *queue;
     unsigned long long *counters; // rays, box, tri, sph, tri_hits, replays

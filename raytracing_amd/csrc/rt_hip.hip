@@ -36,6 +36,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -133,6 +134,20 @@ struct rt_ctx {
     bool pipelining = false;        // rt_set_pipelining: calls may overlap; rt_join / rt_sync order their results
     bool joined = true;             // the context's stream has been made to wait for both pipes
     void *scratch_ptr = nullptr;    // this device's copy of `scratch` (rt_trace_device_noalloc)
+    // rt_trace_begin / rt_trace_end: calls in flight ahead of the caller.  The running mean moves round a ring of three
+    // images -- a begun call continues from the image of the call before it and writes the next one -- so that up to two
+    // begun calls never touch the image of the last ENDED call (ring[ring_at] == d_image), which rt_trace_discard returns to.
+    struct Begun {
+        int img;          // ring index the call writes
+        float *host;      // where its mean is copied
+        hipEvent_t copied;
+    };
+    float4 *ring[3] = {nullptr, nullptr, nullptr}; // ring[ring_at] is d_image; the other two exist once rt_trace_begin has run
+    int ring_at = 0;
+    std::deque<Begun> begun;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_call = nullptr;
+    int next_copied = 0;
     // rt_create_multi: this context only coordinates; kids[r] is an ordinary context on device r of the list, and
     // `device` / `stream` / `d_image` belong to the first device of the list, where the frame is put together.
     std::vector<rt_ctx *> kids;
@@ -345,7 +360,7 @@ double root_box_coverage(const rt_ctx *ctx) {
 // sub-queue always suffice.
 size_t queue_records(size_t items) { return items + kQueueSlack; }
 
-int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim, Plan &pl) {
+int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim, Plan &pl, const float4 *d_img_in = nullptr) {
     if (!ctx->has_scene)
         return fail(ctx, RT_ERR_NO_SCENE, "Scene is not loaded.");
     if (!ctx->has_camera)
@@ -364,6 +379,7 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     P.spheres = ctx->d_spheres;
     P.mats = ctx->d_mats;
     P.image = d_img;
+    P.image_in = d_img_in ? d_img_in : d_img;
     P.primary = d_prim;
     P.queue = ctx->d_queue;
     P.counters = ctx->d_counters;
@@ -488,6 +504,8 @@ int launch_nested(rt_ctx *ctx, const Plan &pl, hipStream_t stream) {
 // pixel, one launch per bounce level (or round), their colours left in ws.colors.  The caller folds them.
 int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t stream, int done, int s_now, KParams &P) {
     P = pl.P;
+    if (done > 0)
+        P.image_in = P.image; // later chunks continue from what the chunk before them folded
     const int first_level = pl.camera ? 1 : 0, levels = pl.levels + first_level;
     RT_HIP_CHECK(ctx, hipMemsetAsync(ws.levels, 0, (size_t)(levels + 1) * kSubQueues * 32 * sizeof(unsigned int), stream));
     P.colors = ws.colors;
@@ -602,14 +620,15 @@ int ensure_workspace(rt_ctx *ctx, rt_ctx::Pipe &pp, size_t need_colors, size_t n
     return RT_OK;
 }
 
-int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim) {
+int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim, const float4 *d_img_in = nullptr,
+                 bool timed = true) {
     Plan pl;
     {
-        const int prc = make_plan(ctx, W, H, first, count, d_img, d_prim, pl);
+        const int prc = make_plan(ctx, W, H, first, count, d_img, d_prim, pl, d_img_in);
         if (prc != RT_OK)
             return prc;
     }
-    if (ctx->pending == ctx->events.size()) {
+    if (timed && ctx->pending == ctx->events.size()) {
         hipEvent_t a, b;
         RT_HIP_CHECK(ctx, hipEventCreate(&a));
         RT_HIP_CHECK(ctx, hipEventCreate(&b));
@@ -622,18 +641,22 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
             if (jrc != RT_OK)
                 return jrc;
         }
-        RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
+        if (timed)
+            RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
         const int nrc = launch_nested(ctx, pl, ctx->stream);
         if (nrc != RT_OK)
             return nrc;
-        RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].second, ctx->stream));
-        ctx->pending++;
+        if (timed) {
+            RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].second, ctx->stream));
+            ctx->pending++;
+        }
         return RT_OK;
     }
     // ---- wavefront: samples in chunks of S; per chunk one launch per bounce level (or round), then k_fold ----
     const int S = chunk_samples(pl, kMaxItems);
     const size_t need_colors = (size_t)S * pl.npix, need_q4 = queue_records((size_t)S * pl.items_per_sample) * pl.rec4;
-    RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
+    if (timed)
+        RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     hipStream_t last_stream = ctx->stream;
     for (int done = 0; done < count; done += S) {
@@ -672,8 +695,10 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
             return jrc;
         last_stream = ctx->stream;
     }
-    RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].second, last_stream));
-    ctx->pending++;
+    if (timed) {
+        RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].second, last_stream));
+        ctx->pending++;
+    }
     return RT_OK;
 }
 
@@ -785,17 +810,37 @@ int ensure_image(rt_ctx *ctx, int width, int height) {
     const size_t px = (size_t)width * (size_t)height;
     if (width != ctx->img_w || height != ctx->img_h || !ctx->d_image) {
         RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_image) (void)hipFree(ctx->d_image);
+        for (float4 *&r : ctx->ring) {
+            if (r) (void)hipFree(r);
+            r = nullptr;
+        }
         if (ctx->d_primary) (void)hipFree(ctx->d_primary);
         ctx->d_image = nullptr;
         ctx->d_primary = nullptr;
         ctx->img_w = ctx->img_h = 0;
-        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_image, px * sizeof(float4)));
+        ctx->ring_at = 0;
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->ring[0], px * sizeof(float4)));
+        ctx->d_image = ctx->ring[0];
         RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_primary, px * sizeof(uint32_t)));
         ctx->img_w = width;
         ctx->img_h = height;
         RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_image, 0, px * sizeof(float4), ctx->stream));
     }
+    return RT_OK;
+}
+
+// Drops what rt_trace_begin has put in flight: waits for it, forgets it; the running mean is the last ended call's again.
+int discard_begun(rt_ctx *ctx) {
+    if (ctx->begun.empty())
+        return RT_OK;
+    {
+        const int src = sync_all(ctx);
+        if (src != RT_OK)
+            return src;
+    }
+    if (ctx->copy_stream)
+        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    ctx->begun.clear();
     return RT_OK;
 }
 
@@ -848,8 +893,14 @@ void destroy_single(rt_ctx *ctx) {
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
-    if (ctx->d_image) (void)hipFree(ctx->d_image);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (float4 *r : ctx->ring)
+        if (r) (void)hipFree(r);
     if (ctx->d_primary) (void)hipFree(ctx->d_primary);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (hipEvent_t e : ctx->ev_copied)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->ev_call) (void)hipEventDestroy(ctx->ev_call);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     for (auto &pp : ctx->pipes) {
@@ -1166,8 +1217,15 @@ int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_
         if (lrc != RT_OK)
             return fail(ctx, lrc, err);
     }
-    if (ctx->kids.empty())
+    if (ctx->kids.empty()) {
+        {
+            DeviceGuard g(ctx->device);
+            const int drc = discard_begun(ctx); // look-ahead calls saw the old scene
+            if (drc != RT_OK)
+                return drc;
+        }
         return upload_layout(ctx, L);
+    }
     for (rt_ctx *k : ctx->kids) { // replicated: every device walks its own copy
         std::lock_guard<std::mutex> klock(k->mu);
         const int rc = upload_layout(k, L);
@@ -1238,6 +1296,9 @@ int rt_reset(rt_ctx *ctx) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     RT_ON_DEVICE(ctx);
     {
+        const int drc = discard_begun(ctx);
+        if (drc != RT_OK)
+            return drc;
         const int jrc = join_pipes(ctx);
         if (jrc != RT_OK)
             return jrc;
@@ -1262,6 +1323,9 @@ int rt_trace(rt_ctx *ctx, int width, int height, int first_sample, int n_samples
     RT_ON_DEVICE(ctx);
     const size_t px = (size_t)width * (size_t)height;
     {
+        const int drc = discard_begun(ctx); // a synchronous call takes over from the last ended call
+        if (drc != RT_OK)
+            return drc;
         const int jrc = join_pipes(ctx); // the image may still be the target of pipelined calls
         if (jrc != RT_OK)
             return jrc;
@@ -1325,6 +1389,103 @@ int rt_trace_device_noalloc(rt_ctx *ctx, int width, int height, int first_sample
 }
 
 uint64_t rt_noalloc_max_pixels(void) { return (uint64_t)kScratchMaxItems; }
+
+int rt_trace_begin(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *out_rgba_mean) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->kids.empty())
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_trace_begin works on a single-device context");
+    if (width <= 0 || height <= 0 || (long long)width * height > 0x7FFFFFFFll || n_samples < 1 || !out_rgba_mean)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad width/height/sample count, or no output buffer");
+    if (ctx->begun.size() >= 2)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "two calls are already in flight: rt_trace_end one first");
+    if (!ctx->has_scene)
+        return fail(ctx, RT_ERR_NO_SCENE, "Scene is not loaded.");
+    RT_ON_DEVICE(ctx);
+    const size_t px = (size_t)width * (size_t)height;
+    if (width != ctx->img_w || height != ctx->img_h || !ctx->d_image) {
+        int rc = discard_begun(ctx);
+        if (rc == RT_OK)
+            rc = join_pipes(ctx);
+        if (rc == RT_OK)
+            rc = ensure_image(ctx, width, height);
+        if (rc != RT_OK)
+            return rc;
+    }
+    if (!ctx->copy_stream) {
+        RT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t &e : ctx->ev_copied)
+            RT_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        RT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_call, hipEventDisableTiming));
+    }
+    for (float4 *&r : ctx->ring)
+        if (!r)
+            RT_HIP_CHECK(ctx, hipMalloc((void **)&r, px * sizeof(float4)));
+    const int from = ctx->begun.empty() ? ctx->ring_at : ctx->begun.back().img, to = (from + 1) % 3;
+    // first_sample == 1 restarts the mean: the folds overwrite every owned pixel, and a share of the frame (tile split)
+    // must find the rest zero
+    if (first_sample == 1 && ctx->opt.tile_world > 1)
+        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->ring[to], 0, px * sizeof(float4), ctx->stream));
+    // the call's chunks are ordered among themselves and behind the call before (the folds chain); nothing makes the
+    // context's stream wait, so this call's kernels overlap the latency-bound end of the one before
+    const bool was = ctx->pipelining;
+    ctx->pipelining = true;
+    const int rc = launch_trace(ctx, width, height, first_sample, n_samples, ctx->ring[to], nullptr, ctx->ring[from], false);
+    ctx->pipelining = was;
+    if (rc != RT_OK)
+        return rc;
+    if (!ctx->joined && ctx->last_fold != nullptr) {
+        RT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->last_fold, 0));
+    } else {
+        RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_call, ctx->stream));
+        RT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_call, 0));
+    }
+    RT_HIP_CHECK(ctx, hipMemcpyAsync(out_rgba_mean, ctx->ring[to], px * sizeof(float4), hipMemcpyDeviceToHost, ctx->copy_stream));
+    hipEvent_t ev = ctx->ev_copied[ctx->next_copied];
+    ctx->next_copied ^= 1;
+    RT_HIP_CHECK(ctx, hipEventRecord(ev, ctx->copy_stream));
+    ctx->begun.push_back(rt_ctx::Begun{to, out_rgba_mean, ev});
+    return RT_OK;
+}
+
+int rt_trace_end(rt_ctx *ctx, rt_stats *stats) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->begun.empty())
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_trace_end without rt_trace_begin");
+    RT_ON_DEVICE(ctx);
+    const rt_ctx::Begun b = ctx->begun.front();
+    RT_HIP_CHECK(ctx, hipEventSynchronize(b.copied));
+    ctx->begun.pop_front();
+    ctx->ring_at = b.img;
+    ctx->d_image = ctx->ring[b.img];
+    if (stats) { // what has run so far: a call begun later may already have added to the counters
+        std::memset(stats, 0, sizeof(*stats));
+        unsigned long long slots[kCounterSlots * kCounterStride], h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        RT_HIP_CHECK(ctx, hipMemcpyAsync(slots, ctx->d_counters, sizeof(slots), hipMemcpyDeviceToHost, ctx->copy_stream));
+        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy_stream));
+        for (int sl = 0; sl < kCounterSlots; sl++)
+            for (int k = 0; k < 8; k++)
+                h[k] += slots[sl * kCounterStride + k];
+        stats->rays = h[0];
+        stats->box_tests = h[1];
+        stats->tri_tests = h[2];
+        stats->sph_tests = h[3];
+        stats->tri_hits = h[4];
+        stats->replays = h[5];
+    }
+    return RT_OK;
+}
+
+int rt_trace_discard(rt_ctx *ctx) {
+    if (!ctx)
+        return RT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    RT_ON_DEVICE(ctx);
+    return discard_begun(ctx);
+}
 
 int rt_set_stream(rt_ctx *ctx, void *hip_stream) {
     if (!ctx)

@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256) k_trace(const KParams P) {
             const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
             float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
             if (P.first_sample > 1)
-                px = P.image[pixel];
+                px = P.image_in[pixel];
             for (int n = P.first_sample; n < P.first_sample + P.n_samples; n++) {
                 Path path;
                 path.o = P.cam_pos;
@@ -989,7 +989,7 @@ __global__ void __launch_bounds__(256) k_fold(const KParams P) {
     }
     float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
     if (P.chunk_first > 1)
-        px = P.image[pixel];
+        px = P.image_in[pixel];
     const unsigned long long mask = P.camera_stage ? P.deferred[pixel] : ~0ull;
     for (int s = 0; s < P.S; s++) {
         const int n = P.chunk_first + s;

@@ -136,6 +136,17 @@ class Tracer:
     def free_host(ptr):
         N.hip().rt_free_host(ptr)
 
+    def trace_begin(self, width, height, first_sample, n_samples, host_rgba_ptr):
+        self._check(N.hip().rt_trace_begin(self._ctx, width, height, first_sample, n_samples, host_rgba_ptr))
+
+    def trace_end(self):
+        st = N.StatsC()
+        self._check(N.hip().rt_trace_end(self._ctx, C.byref(st)))
+        return Stats(st)
+
+    def trace_discard(self):
+        self._check(N.hip().rt_trace_discard(self._ctx))
+
     def trace_device(self, width, height, first_sample, n_samples, d_rgba_ptr, d_primary_ptr=None):
         self._check(N.hip().rt_trace_device(self._ctx, width, height, first_sample, n_samples, d_rgba_ptr,
                                             d_primary_ptr))
@@ -171,10 +182,15 @@ class PluginHarness:
 
     MODE_SD, MODE_OLD = 0, 1
 
-    def __init__(self, mode, width, height, cam, bounce_limit=4, seed=1, jitter=0.001, device=0):
+    def __init__(self, mode, width, height, cam, bounce_limit=4, seed=1, jitter=0.001, device=0, devices=None):
         f = cam.as_floats()
-        self._h = N.host().rth_harness_create(mode, device, width, height, f.ctypes.data_as(C.POINTER(C.c_float)),
-                                              bounce_limit, seed, jitter)
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*devices)
+            self._h = N.host().rth_harness_create_devices(mode, ids, len(devices), width, height,
+                                                          f.ctypes.data_as(C.POINTER(C.c_float)), bounce_limit, seed, jitter)
+        else:
+            self._h = N.host().rth_harness_create(mode, device, width, height, f.ctypes.data_as(C.POINTER(C.c_float)),
+                                                  bounce_limit, seed, jitter)
         if not self._h:
             raise RuntimeError(N.host().rth_last_error().decode())
 
@@ -188,6 +204,9 @@ class PluginHarness:
     def _call(self, fn, *a):
         if fn(self._h, *a) != 0:
             raise RuntimeError(N.host().rth_last_error().decode())
+
+    def set_look_ahead(self, on):
+        N.host().rth_harness_set_look_ahead(self._h, 1 if on else 0)
 
     def load(self):
         self._call(N.host().rth_harness_load)
