@@ -21,6 +21,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E nominal
 VALU_PEAK_TOPS = 78.6         # 256 CU x 128 lanes x 2.4 GHz, one op per lane-cycle (the path forbids FMA contraction)
 L2_BYTES = 32 << 20           # 8 XCDs x 4 MB: scenes whose node + triangle-position records fit are served from the L2s
+MALL_BYTES = 256 << 20        # Infinity Cache: scenes up to this size are served on-die as well (measured: the 133 MB field)
 
 
 def host_cpu():
@@ -253,21 +254,25 @@ def main():
             with open(ppath) as fh:
                 pmc = json.load(fh).get(f"{wl.name}:{my_spp}", {})
         traffic = pmc.get("hbm_bytes_per_step")
-        in_l2 = wl.scene_bytes() <= L2_BYTES
-        if in_l2:
-            # node and triangle records are served by the L2s: what bounds the walk is VALU issue under divergence
+        scene_bytes = wl.scene_bytes()
+        on_die = scene_bytes <= MALL_BYTES
+        if on_die:
+            # node and triangle records are served by the L2s (<= 32 MB) or the Infinity Cache (<= 256 MB): HBM carries the
+            # queues and the image only, and what bounds the walk is VALU issue under divergence (and the latency behind it)
             roof = {"bound": "valu", "achieved": alg_ops / secs / 1e12, "peak": VALU_PEAK_TOPS, "unit": "Tops/s",
                     "frac": alg_ops / secs / 1e12 / VALU_PEAK_TOPS, "traffic": traffic,
                     "algorithmic_ops_per_launch": int(alg_ops),
                     "note": "fp32 lane-operations the walk's own tests and the shading need (27 per slab test, 56 per "
-                            "triangle test, 24 per sphere test, 60 per ray) against the non-FMA VALU peak; the scene's "
-                            "records fit the L2s, so HBM carries only the queues and the image (hbm_*)"}
+                            "triangle test, 24 per sphere test, 60 per ray) against the non-FMA VALU peak; the scene's records ("
+                            + "%.1f MB) are served by the %s, so HBM carries only the queues and the image (hbm_*)"
+                            % (scene_bytes / 1e6, "L2s" if scene_bytes <= L2_BYTES else "Infinity Cache")}
         else:
             roof = {"bound": "hbm", "achieved": alg_bytes / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": alg_bytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(alg_bytes),
                     "note": "bytes the walk's own tests need (32 per slab test, 36 per triangle test, 36 of normals per "
-                            "triangle hit) + the image; the scene's records exceed the L2s"}
+                            "triangle hit) + the image; the scene's records (%.0f MB) exceed every cache" % (scene_bytes / 1e6)}
+        roof["valu_frac"] = alg_ops / secs / 1e12 / VALU_PEAK_TOPS
         roof.update({"kernel": "one step = one trace call: k_sliced (flat scenes within the L2s), k_path (pointer scenes) or "
                                "k_refill (beyond the L2s), one launch per round / bounce level and chunk of samples, + k_fold",
                      "kernel_ms": kernel_ms,
