@@ -82,7 +82,7 @@ def cpu_baseline(wl, args):
                          threads=threads, lock_per_pixel=0, accum=O.ACCUM_FORWARD)
     # The sample is sized from a probe (1 spp at 1/32 of the resolution) so that each of the two timed renders is about
     # args.cpu_seconds of CPU work whatever the workload costs per ray: the largest resolution among 1/4 ... 1/32 at
-    # which one sample per pixel fits, and as many samples per pixel as fit (at most 256).
+    # which one sample per pixel fits, and as many samples per pixel as fit.
     pw, ph = max(wl.width // 32, 16), max(wl.height // 32, 9)
     _, _, probe = osc.render(ocam, opt, pw, ph, 1, 1)
     per_pixel = max(probe.seconds, 1e-5) / (pw * ph)
@@ -90,7 +90,10 @@ def cpu_baseline(wl, args):
     while div < 32 and per_pixel * (wl.width // div) * (wl.height // div) > args.cpu_seconds:
         div *= 2
     w, h = max(wl.width // div, 16), max(wl.height // div, 9)
-    spp = args.cpu_spp or int(min(max(args.cpu_seconds / (per_pixel * w * h), 1), 256))
+    if per_pixel * w * h < 0.25 * args.cpu_seconds:  # cheap rays: the small probe mostly measured thread start-up; probe again at size
+        _, _, probe = osc.render(ocam, opt, w, h, 1, 1)
+        per_pixel = max(probe.seconds, 1e-5) / (w * h)
+    spp = args.cpu_spp or int(min(max(args.cpu_seconds / (per_pixel * w * h), 1), 4096))
     args.cpu_spp = spp
     _, _, st = osc.render(ocam, opt, w, h, 1, spp)
     # (i) the reference's own schedule: 16 row bands per sample and a shared_lock per pixel (TraceMethods.cpp:57, :61-78)
