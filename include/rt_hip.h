@@ -158,7 +158,10 @@ typedef struct rt_options {
     float jitter;         /* perturbStrength, Renderer/TraceMethods.cpp:48 */
     int32_t tile_rank;    /* this context renders 8x8 tiles k with k % tile_world == tile_rank */
     int32_t tile_world;   /* 1 = whole image */
-    int32_t collect_stats; /* also count slab / triangle / sphere tests (slower kernel variant) */
+    int32_t collect_stats; /* also count slab / triangle / sphere tests (slower kernel variant; it steps through the
+                              exact 32-byte tree records, so the counts are those of the CPU restatement's walk, where
+                              a trace without statistics may take the 16-byte grid records of a flat scene: more box
+                              tests, the same hits) */
     uint32_t sample_offset; /* added to the sample index in the RNG key only: lets several contexts each
                                accumulate a mean over n samples of disjoint random streams (sample-range split) */
     int32_t traversal;      /* RT_TRAV_* */

@@ -30,7 +30,8 @@ constexpr int kMaxLevels = 64;             // bounce levels a wavefront trace ca
 constexpr uint32_t kTailRays = 256u << 10;  // a level with no more rays than this follows every path to its end in one launch
 constexpr uint32_t kSlice = 128;            // k_sliced: records a ray is taken further per round
 constexpr int kSliceBurst = 32;            // k_sliced: records between two looks at the wave's list of noted tests
-constexpr int kSliceExtraRounds = 2;       // k_sliced: launches beyond one per bounce level (the last one finishes whatever is left)
+constexpr int kSliceExtraRounds = 0;       // k_sliced: launches beyond one per bounce level (the last one finishes whatever is left)
+constexpr uint32_t kSliceTailRays = 2u << 20; // k_sliced: a round with no more rays than this is finished by the re-fill kernel
 constexpr int kChunkSamples = 64;          // samples per pixel traced per wavefront chunk
 constexpr size_t kMaxItems = 192u << 20;   // work items (pixel samples) per chunk: bounds the queue workspace
 
@@ -38,6 +39,11 @@ constexpr size_t kMaxItems = 192u << 20;   // work items (pixel samples) per chu
 struct KParams {
     const float4 *nodes; // 2 x float4 per node, reference visiting order
     const float4 *fnodes; // 2 x float4 per node of the fast tree (pre-order, exact-union boxes over the reference's leaf boxes)
+    const uint4 *cnodes;       // compact fast tree (flat scenes): 16 bytes per node, see SceneLayout::cn
+    const float4 *leaf_boxes;  // ... and its leaves: triangle and exact box, 4 x float4 per triangle slot
+    f3 q_origin, q_step;       // ... and the grid its 16-bit planes live on
+    int compact;               // the sliced / re-fill walks go over the compact tree
+    int refill_tail;           // k_sliced leaves a round of at most tail_rays rays to the re-fill kernel launched before it
     const float4 *tri_pos; // 3 x float4 per triangle slot: p0, e1, e2, prim id, material
     const float4 *tri_nrm; // 3 x float4 per triangle slot: n0, n1, n2
     const float4 *spheres; // 2 x float4 per sphere

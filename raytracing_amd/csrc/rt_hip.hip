@@ -97,6 +97,10 @@ struct rt_ctx {
     uint32_t n_fnodes = 0;
     float4 *d_nodes = nullptr, *d_tri_pos = nullptr, *d_tri_nrm = nullptr, *d_spheres = nullptr, *d_mats = nullptr;
     uint32_t n_nodes = 0;
+    float4 *d_cnodes = nullptr, *d_leaf_boxes = nullptr; // compact fast tree of a flat scene (SceneLayout::cn, lb)
+    float q_origin[3] = {0, 0, 0}, q_step[3] = {1, 1, 1};
+    bool has_compact = false;
+    double compact_inflation = 1.0;
     bool has_scene = false;
     size_t scene_bytes = 0; // fast-tree records + triangle positions
     bool fast_exact = true; // the uploaded tree's interior boxes contain their children's (see build_layout)
@@ -222,6 +226,10 @@ void free_scene(rt_ctx *c) {
     if (c->d_tri_nrm) (void)hipFree(c->d_tri_nrm);
     if (c->d_spheres) (void)hipFree(c->d_spheres);
     if (c->d_mats) (void)hipFree(c->d_mats);
+    if (c->d_cnodes) (void)hipFree(c->d_cnodes);
+    if (c->d_leaf_boxes) (void)hipFree(c->d_leaf_boxes);
+    c->d_cnodes = c->d_leaf_boxes = nullptr;
+    c->has_compact = false;
     c->d_nodes = c->d_tri_pos = c->d_tri_nrm = c->d_spheres = c->d_mats = nullptr;
     c->n_nodes = 0;
     c->has_scene = false;
@@ -293,8 +301,10 @@ int sync_all(rt_ctx *ctx) {
 // The tracer's tuning constants; each can be overridden from the environment for measurements (RT_SLICE, RT_TAIL_RAYS,
 // RT_EXTRA_ROUNDS, RT_CHUNK_SAMPLES), read once per process.  Results do not depend on them.
 struct Tuning {
-    uint32_t slice = kSlice, tail_rays = kTailRays;
+    uint32_t slice = kSlice, tail_rays = kTailRays, slice_tail_rays = kSliceTailRays;
     int extra_rounds = kSliceExtraRounds, chunk_samples = kChunkSamples;
+    int compact = 1; // RT_COMPACT=0: no walk takes the compact tree; 2: traces that collect statistics take it too
+    int refill_tail = 1; // RT_REFILL_TAIL=0: k_sliced finishes its last round itself
 };
 const Tuning &tuning() {
     static const Tuning t = [] {
@@ -308,8 +318,11 @@ const Tuning &tuning() {
         };
         v.slice = (uint32_t)env("RT_SLICE", 1, 1 << 20, kSlice);
         v.tail_rays = (uint32_t)env("RT_TAIL_RAYS", 0, 1 << 30, kTailRays);
-        v.extra_rounds = (int)env("RT_EXTRA_ROUNDS", 0, 32, kSliceExtraRounds);
+        v.slice_tail_rays = (uint32_t)env("RT_TAIL_RAYS", 0, 1 << 30, kSliceTailRays);
+        v.extra_rounds = (int)env("RT_EXTRA_ROUNDS", -32, 32, kSliceExtraRounds);
         v.chunk_samples = (int)env("RT_CHUNK_SAMPLES", 1, kChunkSamples, kChunkSamples);
+        v.compact = (int)env("RT_COMPACT", 0, 2, 1);
+        v.refill_tail = (int)env("RT_REFILL_TAIL", 0, 1, 1);
         return v;
     }();
     return t;
@@ -322,6 +335,7 @@ struct Plan {
     bool nested = false, sliced = false, queued = false, refill = false;
     bool camera = false;        // the chunk starts with k_camera, the path kernels run at levels 1 .. levels
     uint32_t full_grid = 1;
+    bool compact = false;       // the sliced walk steps through the compact tree
     size_t rec4 = 4;            // float4 per queue record
     size_t npix = 0, items_per_sample = 0;
     int W = 0, H = 0, first = 1, count = 0;
@@ -425,11 +439,12 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     if (trav == RT_TRAV_REFERENCE)
         trav = ctx->expected_visits >= 512.0 ? RT_TRAV_WAVE : RT_TRAV_LANE;
     P.force_replay = trav == RT_TRAV_FAST_REPLAY ? 1 : 0;
-    // RT_TRAV_FAST: lane re-fill pays when walks are long and their fetches miss the L2 -- scenes whose fast tree and
-    // triangle positions exceed the L2s; smaller scenes take k_path with the noted primitive tests.
-    pl.refill = trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && ctx->scene_bytes > kRefillSceneBytes);
-    // ... among those, the flat scene in slices (measured +5 %; the sphere scene loses 7 % in slices)
-    pl.sliced = trav == RT_TRAV_FAST_SLICED || (trav == RT_TRAV_FAST && !pl.refill && !old);
+    // RT_TRAV_FAST: the loop estimator's scenes are walked in slices, rounds that no longer fill the chip finished with lane
+    // re-fill (measured against re-fill alone: level on the 907 k-triangle pair, 10 to 20 % ahead on the other scenes,
+    // small and large).  The recursive estimator's scenes (spheres, mesh objects): lane re-fill when the fast tree and
+    // triangle positions exceed the L2s, k_path with the noted primitive tests otherwise.
+    pl.refill = trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && old && ctx->scene_bytes > kRefillSceneBytes);
+    pl.sliced = trav == RT_TRAV_FAST_SLICED || (trav == RT_TRAV_FAST && !old);
     pl.queued = trav == RT_TRAV_FAST_QUEUED || (trav == RT_TRAV_FAST && !pl.refill && !pl.sliced);
     if (trav == RT_TRAV_FAST_QUEUED || trav == RT_TRAV_FAST_INLINE || trav == RT_TRAV_FAST_SLICED || trav == RT_TRAV_FAST_REFILL)
         trav = RT_TRAV_FAST;
@@ -447,6 +462,8 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
         pl.levels += tuning().extra_rounds;
         if (pl.levels > kMaxLevels - 1)
             pl.levels = kMaxLevels - 1;
+        if (pl.levels < 2)
+            pl.levels = 2;
     }
     // Camera stage: worth it when most camera rays miss the scene altogether -- judged by the part of the frame the root
     // box's projection covers -- and possible when the walk is the fast tree's (the stage tests that tree's root record).
@@ -458,8 +475,24 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     P.camera_stage = pl.camera ? 1 : 0;
     P.deferred = nullptr;
     P.slice = tuning().slice;
-    P.tail_rays = tuning().tail_rays;
+    P.tail_rays = pl.sliced && tuning().refill_tail != 0 ? tuning().slice_tail_rays : tuning().tail_rays;
     pl.rec4 = pl.sliced ? 6 : 4;
+    // Compact tree: when the scene has one and every ray of the call starts close enough to it for the grid arithmetic's
+    // margin (compact_walk_from): bounce rays start on the geometry, the camera within 32 grid extents per axis.
+    P.cnodes = (const uint4 *)ctx->d_cnodes;
+    P.leaf_boxes = ctx->d_leaf_boxes;
+    P.q_origin = mk3(ctx->q_origin[0], ctx->q_origin[1], ctx->q_origin[2]);
+    P.q_step = mk3(ctx->q_step[0], ctx->q_step[1], ctx->q_step[2]);
+    // A trace that collects statistics walks the exact records: its counters then describe the walk the other kernels and
+    // the CPU restatement make, test for test (the compact walk makes more box tests, with the same outcome).
+    pl.compact = pl.walk == WALK_FAST && (pl.sliced || pl.refill) && !old && (!st || tuning().compact == 2) && ctx->has_compact &&
+                 tuning().compact != 0;
+    for (int k = 0; k < 3 && pl.compact; k++) {
+        const float ext = ctx->q_step[k] * 65536.0f, rel = c.position[k] - ctx->q_origin[k];
+        if (!(rel > -32.0f * ext && rel < 33.0f * ext))
+            pl.compact = false;
+    }
+    P.compact = pl.compact ? 1 : 0;
     P.npix = (uint32_t)pl.npix;
     pl.W = W;
     pl.H = H;
@@ -516,6 +549,7 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
     P.n_items = (uint32_t)((size_t)s_now * pl.items_per_sample);
     P.sub_cap = (((P.n_items + 63u) / 64u) / (uint32_t)kSubQueues + 66u) * 64u;
     const bool sliced = pl.sliced, queued = pl.queued, refill = pl.refill;
+    const bool refill_tail = tuning().refill_tail != 0; // the sliced walk's last round is finished with lane re-fill
     const int walk = pl.walk;
     dim3 block(256);
     if (pl.camera) { // level 0: camera rays, root slab test; what passes goes to level 1's queue
@@ -564,14 +598,38 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
         // fetch latency; the spills land in the shading code, which runs once per ray); the others: uncapped
 #define RT_LAUNCH_PATH(OLD_, STATS_)                                                                                  \
     do {                                                                                                              \
-        if (walk == WALK_FAST && sliced) hipLaunchKernelGGL((k_sliced<OLD_, STATS_>), grid, block, 0, stream, P);     \
+        if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail && !OLD_ && pl.compact) hipLaunchKernelGGL((k_refill<false, STATS_, true, true>), grid, block, 0, stream, P); \
+        else if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail) hipLaunchKernelGGL((k_refill<OLD_, STATS_, false, true>), grid, block, 0, stream, P); \
+        else if (walk == WALK_FAST && sliced && !OLD_ && pl.compact) hipLaunchKernelGGL((k_sliced<false, STATS_, true>), grid, block, 0, stream, P); \
+        else if (walk == WALK_FAST && sliced) hipLaunchKernelGGL((k_sliced<OLD_, STATS_>), grid, block, 0, stream, P); \
         else if (walk == WALK_FAST && queued) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_QUEUED>), grid, block, 0, stream, P); \
         else if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, 0, stream, P); \
+        else if (walk == WALK_FAST && refill && !OLD_ && pl.compact) hipLaunchKernelGGL((k_refill<false, STATS_, true>), grid, block, 0, stream, P); \
         else if (walk == WALK_FAST && refill) hipLaunchKernelGGL((k_refill<OLD_, STATS_>), grid, block, 0, stream, P); \
         else if (walk == WALK_FAST) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_FAST>), grid, block, 0, stream, P); \
         else if (walk == WALK_BRUTE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_BRUTE>), grid, block, 0, stream, P); \
         else hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_LANE>), grid, block, 0, stream, P);                         \
     } while (0)
+        // The sliced walk hands a round that no longer fills the chip to the re-fill kernel: launched first, it takes the
+        // round only if it is that small (and then k_sliced, launched after it, leaves at once); the last round is always its.
+        if (walk == WALK_FAST && sliced && refill_tail && level >= 1 && level < levels - 1) {
+            P.refill_tail = 1;
+            switch (pl.variant) {
+            case 4:
+                if (pl.compact) hipLaunchKernelGGL((k_refill<false, false, true, true>), grid, block, 0, stream, P);
+                else hipLaunchKernelGGL((k_refill<false, false, false, true>), grid, block, 0, stream, P);
+                break;
+            case 5:
+                if (pl.compact) hipLaunchKernelGGL((k_refill<false, true, true, true>), grid, block, 0, stream, P);
+                else hipLaunchKernelGGL((k_refill<false, true, false, true>), grid, block, 0, stream, P);
+                break;
+            case 6: hipLaunchKernelGGL((k_refill<true, false, false, true>), grid, block, 0, stream, P); break;
+            default: hipLaunchKernelGGL((k_refill<true, true, false, true>), grid, block, 0, stream, P); break;
+            }
+            RT_HIP_CHECK(ctx, hipGetLastError());
+        } else {
+            P.refill_tail = 0;
+        }
         switch (pl.variant) {
         case 4: RT_LAUNCH_PATH(false, false); break;
         case 5: RT_LAUNCH_PATH(false, true); break;
@@ -860,6 +918,19 @@ int upload_layout(rt_ctx *ctx, const SceneLayout &L) {
         (rc = upload(ctx, &ctx->d_spheres, L.sp)) != RT_OK || (rc = upload(ctx, &ctx->d_mats, L.mt)) != RT_OK) {
         free_scene(ctx);
         return rc;
+    }
+    if (L.compact) {
+        if ((rc = upload(ctx, &ctx->d_cnodes, L.cn)) != RT_OK || (rc = upload(ctx, &ctx->d_leaf_boxes, L.lb)) != RT_OK) {
+            free_scene(ctx);
+            return rc;
+        }
+        std::memcpy(ctx->q_origin, L.q_origin, sizeof(ctx->q_origin));
+        std::memcpy(ctx->q_step, L.q_step, sizeof(ctx->q_step));
+        ctx->has_compact = true;
+        ctx->compact_inflation = L.compact_inflation;
+        if (std::getenv("RT_DEBUG_LAYOUT"))
+            std::fprintf(stderr, "compact inflation %.4f expected visits %.2f fast visits %.2f scene bytes %zu\n", L.compact_inflation, L.expected_visits, L.fast_visits,
+                         (L.fn.size() + L.tp.size()) * sizeof(float4));
     }
     ctx->expected_visits = L.expected_visits;
     if (L.fn.size() >= 2) {

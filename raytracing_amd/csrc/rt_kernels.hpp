@@ -482,6 +482,33 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : (WALK == WALK_QUE
     }
 }
 
+// What a lane of the compact walk does with a leaf record that passed its grid box: the leaf goes on the wave's list
+// (resolve_jobs_compact); with no room there, its exact box test and triangle test run on the spot.
+template <bool STATS>
+RT_D void note_leaf(const KParams &P, const uint32_t lane, const uint32_t slot, const Path &path, WaveJobs &J, Best &best, uint32_t &bpos,
+                    float &bm, Cnt &cnt) {
+    const uint32_t j = atomicAdd(&J.count, 1u);
+    if (j < kJobCap && slot < kJobSphere) {
+        J.jobs[j] = make_uint2((lane << kJobSlotBits) | slot, 0u);
+        return;
+    }
+    float m, t, u, v;
+    if (STATS)
+        cnt.box++;
+    const float4 q0 = P.leaf_boxes[4 * slot], q1 = P.leaf_boxes[4 * slot + 1], q2 = P.leaf_boxes[4 * slot + 2], q3 = P.leaf_boxes[4 * slot + 3];
+    if (!exact_leaf_entry(q2, q3, path.o, path.inv, m))
+        return;
+    if (STATS)
+        cnt.tri++;
+    const uint32_t pos = __float_as_uint(q2.w);
+    if (tri_test(path.o, path.d, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), t, u, v) &&
+        (t < best.t || (t == best.t && pos < bpos)) && t < __builtin_inff()) {
+        best = Best{t, u, v, slot};
+        bpos = pos;
+        bm = m;
+    }
+}
+
 // Path kernel of the fast walk with lane re-fill (one launch per bounce level, like k_path).
 //
 // Walk lengths are heavy-tailed, so a wave that takes 64 rays and walks until the longest one is done has, at the
@@ -495,8 +522,11 @@ constexpr int kBurst = 16;
 constexpr uint32_t kServiceLanes = 24;
 constexpr size_t kRefillSceneBytes = 32u << 20; // 8 XCDs x 4 MB of L2
 
-template <bool OLD, bool STATS>
+// WALKS = true: the kernel finishes a round of k_sliced -- its queue holds that kernel's six-float4 records, rays in the
+// middle of their walks among them -- and follows every path to its end (tail mode).
+template <bool OLD, bool STATS, bool COMPACT = false, bool WALKS = false>
 __global__ void __launch_bounds__(256) k_refill(const KParams P) {
+    constexpr size_t R4 = WALKS ? 6 : 4; // float4 per queue record
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     // Primitive tests are taken out of the walk as in closest_hit_fast_queued: lanes note them, the wave runs them together
@@ -523,13 +553,15 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
     }
     if (n_batches == 0u)
         return;
-    const bool tail = P.tail != 0 || (P.level >= 1 && n_batches * 64u <= P.tail_rays);
+    if (WALKS && P.tail == 0 && n_batches * 64u > P.tail_rays)
+        return; // a round that still fills the chip: k_sliced, launched next, takes it
+    const bool tail = WALKS || P.tail != 0 || (P.level >= 1 && n_batches * 64u <= P.tail_rays);
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t my_q = wave_id & (uint32_t)(kSubQueues - 1);
     const uint32_t my_count = P.level == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sub_count, (int)my_q);
     const uint32_t my_batches = P.level == 0 ? (n_batches > my_q ? (n_batches - my_q + (uint32_t)kSubQueues - 1u) / (uint32_t)kSubQueues : 0u)
                                              : (my_count + 63u) >> 6;
-    const uint32_t n = P.n_fnodes * 32u;
+    const uint32_t n = P.n_fnodes * (COMPACT ? 16u : 32u); // a walk's position is a byte offset into the array it steps through
     // the batch the wave is handing out, and how many of its 64 items are gone (64 = none held)
     uint32_t cur_b = 0u, used = 64u;
     bool drained = my_batches == 0u; // the group's cursor has run past its last batch
@@ -546,8 +578,11 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
     Best best = {__builtin_inff(), 0.0f, 0.0f, kNone};
     uint32_t bpos = kNone;
     float bm = 0.0f;
+    GridRay grid = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
     auto start_walk = [&]() {
         path.inv = mk3(1.0f / path.d.x, 1.0f / path.d.y, 1.0f / path.d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
+        if (COMPACT)
+            grid = grid_ray(P, path.o, path.inv);
         w = Walk{0u, kNone, kNone, 0.0f};
         best = Best{__builtin_inff(), 0.0f, 0.0f, kNone};
         bpos = kNone;
@@ -581,10 +616,11 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
                     out_q = my_q;
                 } else if (cur_b * 64u + item < my_count) {
                     const size_t g = (size_t)my_q * P.sub_cap + (size_t)cur_b * 64u + item;
+                    bool walking = false;
                     if (P.camera_stage != 0 && P.level == 1) {
-                        read_camera_record(P, P.q_in[4 * ((size_t)my_q * P.sub_cap) + ((size_t)cur_b * 64u + item)], path, cidx);
+                        read_camera_record(P, P.q_in[R4 * ((size_t)my_q * P.sub_cap) + ((size_t)cur_b * 64u + item)], path, cidx);
                     } else {
-                        const float4 r0 = P.q_in[4 * g], r1 = P.q_in[4 * g + 1], r2 = P.q_in[4 * g + 2], r3 = P.q_in[4 * g + 3];
+                        const float4 r0 = P.q_in[R4 * g], r1 = P.q_in[R4 * g + 1], r2 = P.q_in[R4 * g + 2], r3 = P.q_in[R4 * g + 3];
                         path.o = mk3(r0.x, r0.y, r0.z);
                         path.d = mk3(r0.w, r1.x, r1.y);
                         path.thr = make_float4(r1.z, r1.w, r2.x, r2.y);
@@ -592,11 +628,25 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
                         path.key = __float_as_uint(r2.w);
                         cidx = __float_as_uint(r3.x);
                         path.depth = (int)__float_as_uint(r3.y);
+                        if (WALKS && __float_as_uint(r3.z) != 0u) { // a ray in the middle of its walk (a walk never returns to record 0)
+                            const float4 r4 = P.q_in[R4 * g + 4], r5 = P.q_in[R4 * g + 5];
+                            walking = true;
+                            path.inv = mk3(1.0f / path.d.x, 1.0f / path.d.y, 1.0f / path.d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
+                            if (COMPACT)
+                                grid = grid_ray(P, path.o, path.inv);
+                            w = Walk{__float_as_uint(r3.z), __float_as_uint(r5.w), __float_as_uint(r5.y), r5.z};
+                            best = Best{r4.x, r4.y, r4.z, __float_as_uint(r3.w)};
+                            bpos = __float_as_uint(r4.w);
+                            bm = r5.x;
+                            J.key[lane] = ~0ull;
+                        }
                     }
                     out_q = (my_q + cur_b) & (uint32_t)(kSubQueues - 1);
                     has = true;
+                    if (!walking)
+                        start_walk();
                 }
-                if (has)
+                if (has && P.level == 0)
                     start_walk();
             }
             const uint32_t taken = (uint32_t)__builtin_popcountll(empty);
@@ -608,7 +658,10 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
             break; // nothing in flight and nothing left to hand out
         // ---- walk in bursts until enough lanes wait for service ----
         for (;;) {
-            if (has && w.idx < n) {
+            if (COMPACT && has && w.idx < n) {
+                compact_walk_from<STATS>(P, path.inv, grid, w.idx, kBurst, cnt,
+                                         [&](const uint32_t slot) { note_leaf<STATS>(P, lane, slot, path, J, best, bpos, bm, cnt); });
+            } else if (has && w.idx < n) {
                 fast_walk_from<OLD, STATS, kBurst>(P, path.o, path.d, path.inv, w, cnt, [&](const Cand &c) {
                     if ((c.t < best.t || (c.t == best.t && c.pos < bpos)) && c.t < __builtin_inff()) {
                         best = Best{c.t, c.u, c.v, c.ref};
@@ -624,8 +677,12 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
                 });
             }
             __builtin_amdgcn_wave_barrier();
-            if (J.count + 64u * (uint32_t)kBurst / 4u > kJobCap) // the next burst could overflow the list: run what is noted
-                resolve_jobs<OLD>(P, lane, path.o, path.d, J);
+            if (J.count + 64u * (uint32_t)kBurst / 4u > kJobCap) { // the next burst could overflow the list: run what is noted
+                if (COMPACT)
+                    resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt);
+                else
+                    resolve_jobs<OLD>(P, lane, path.o, path.d, J);
+            }
             const unsigned long long walking = __ballot(has && w.idx < n);
             if (walking == 0ull)
                 break;
@@ -635,7 +692,10 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
                 break;
         }
         // ---- shade the finished walks ----
-        resolve_jobs<OLD>(P, lane, path.o, path.d, J);
+        if (COMPACT)
+            resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt);
+        else
+            resolve_jobs<OLD>(P, lane, path.o, path.d, J);
         take_noted_result(has && !(w.idx < n), lane, J, best, bpos, bm);
         bool cont = false;
         if (has && !(w.idx < n)) {
@@ -700,7 +760,7 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
 // end of the slice (WaveJobs), so that the dense walk is not interrupted for the few lanes that stand on a leaf.  A round
 // whose queue cannot fill the chip finishes everything in place (tail mode, as k_path).  Records are six float4: the
 // four of k_path plus the walk.  Same per-ray arithmetic as k_path, same results.
-template <bool OLD, bool STATS>
+template <bool OLD, bool STATS, bool COMPACT = false>
 __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -724,6 +784,8 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
     if (n_batches == 0u)
         return;
     const uint32_t n_in = P.level == 0 ? P.n_items : n_batches * 64u;
+    if (P.refill_tail != 0 && P.level >= 1 && n_in <= P.tail_rays)
+        return; // finished by the re-fill kernel launched before this one
     const bool tail = P.tail != 0 || (P.level >= 1 && n_in <= P.tail_rays);
     const int slice = tail ? 0x7FFFFFFF : (int)P.slice;
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -733,7 +795,7 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
     const uint32_t my_batches = P.level == 0 ? (n_batches > my_q ? (n_batches - my_q + (uint32_t)kSubQueues - 1u) / (uint32_t)kSubQueues : 0u)
                                              : (my_count + 63u) >> 6;
     const uint32_t chunk = P.level == 0 ? kChunk : 1u;
-    const uint32_t n = P.n_fnodes * 32u;
+    const uint32_t n = P.n_fnodes * (COMPACT ? 16u : 32u); // a walk's position is a byte offset into the array it steps through
     J.key[lane] = ~0ull;
     if (lane == 0)
         J.count = 0u;
@@ -809,8 +871,14 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
             // The slice is walked in bursts; between two bursts the wave runs the tests noted so far if its list is more than
             // half full.  A full list makes the walk test on the spot, a few lanes at a time, which costs far more than a
             // pass of resolve_jobs (the minima per owner stay in the wave's LDS words from one pass to the next).
+            GridRay grid;
+            if (COMPACT)
+                grid = grid_ray(P, path.o, path.inv);
             for (int left = slice;;) {
-                if (live && w.idx < n) {
+                if (COMPACT && live && w.idx < n) {
+                    compact_walk_from<STATS>(P, path.inv, grid, w.idx, left < kSliceBurst ? left : kSliceBurst, cnt,
+                                             [&](const uint32_t slot) { note_leaf<STATS>(P, lane, slot, path, J, best, bpos, bm, cnt); });
+                } else if (live && w.idx < n) {
                     w.slice = left < kSliceBurst ? left : kSliceBurst;
                     fast_walk_from<OLD, STATS, -1>(P, path.o, path.d, path.inv, w, cnt, [&](const Cand &c) {
                         if ((c.t < best.t || (c.t == best.t && c.pos < bpos)) && c.t < __builtin_inff()) {
@@ -830,11 +898,18 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
                 __builtin_amdgcn_wave_barrier();
                 if (left == 0 || __ballot(live && w.idx < n) == 0ull)
                     break;
-                if (J.count > kJobCap / 2u)
-                    resolve_jobs<OLD>(P, lane, path.o, path.d, J);
+                if (J.count > kJobCap / 2u) {
+                    if (COMPACT)
+                        resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt);
+                    else
+                        resolve_jobs<OLD>(P, lane, path.o, path.d, J);
+                }
             }
             // the noted tests of this slice, then every lane's best is complete up to where its walk stands
-            resolve_jobs<OLD>(P, lane, path.o, path.d, J);
+            if (COMPACT)
+                resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt);
+            else
+                resolve_jobs<OLD>(P, lane, path.o, path.d, J);
             take_noted_result(live, lane, J, best, bpos, bm);
             J.key[lane] = ~0ull;
             if (live && !(w.idx < n)) {

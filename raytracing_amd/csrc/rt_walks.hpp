@@ -694,6 +694,148 @@ RT_D void resolve_jobs(const KParams &P, const uint32_t lane, const f3 o, const 
     __builtin_amdgcn_wave_barrier();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The compact walk (flat scenes).  The fast walk's interior boxes only have to be conservative -- what it returns is
+// decided by the leaves that pass their own exact test -- so the records it steps through can be half the size: six
+// 16-bit grid planes that enclose the node's box with a grid unit to spare, and one word (KParams::cnodes).  A plane's
+// distance along the ray is one fused multiply-add, t = q * (step * inv) + (origin - o) * inv; its rounding error stays
+// below 0.4 grid units for a ray that starts within 32 grid extents of the grid's origin -- and the reference's own slab
+// test, which rounds too, stays within another 0.3 -- (checked per call for the
+// camera; bounce rays start on the geometry), so a record whose exact box the ray meets always passes.  A LEAF record
+// that passes is only noted; its exact box test (the reference's leaf box, bit for bit: it yields the entry distance the
+// acceptance rule needs) runs with its triangle test, 64 jobs at a time, from one 64-byte record that holds both
+// (KParams::leaf_boxes).  One 16-byte load per step instead of two.
+struct GridRay {
+    f3 A, B; // t = q * A + B
+};
+// One axis.  A direction component of (nearly) zero makes 1 / d infinite (or so large that the products overflow), and
+// infinity times a plane's number minus infinity is not a number: the axis would stop pruning anything, and a ray along a
+// coordinate axis -- straight up from the ground, say -- would visit every record of the tree.  What the slab test means
+// there is "is the origin between the two planes": t = (q - q_o) * (+-1e30), q_o the origin in grid units, says just that,
+// and dwarfs every distance the other axes (|d| = 1: one of them has |1 / d| < 1.8) can produce.
+RT_D void grid_axis(const float step, const float origin, const float o, const float inv, float &A, float &B) {
+    if (__builtin_fabsf(inv) > 1e25f) {
+        A = __builtin_copysignf(1e30f, inv);
+        B = -((o - origin) / step) * A;
+    } else {
+        A = step * inv;
+        B = (origin - o) * inv;
+    }
+}
+RT_D GridRay grid_ray(const KParams &P, const f3 o, const f3 inv) {
+    GridRay g;
+    grid_axis(P.q_step.x, P.q_origin.x, o.x, inv.x, g.A.x, g.B.x);
+    grid_axis(P.q_step.y, P.q_origin.y, o.y, inv.y, g.A.y, g.B.y);
+    grid_axis(P.q_step.z, P.q_origin.z, o.z, inv.z, g.A.z, g.B.z);
+    return g;
+}
+
+// The reference's slab test of a leaf box with closest = +inf (SimplifiedData.cpp:146-161 as the fast walk evaluates it):
+// true when the ray meets the box, with the entry distance max(near planes, 1e-6).
+RT_D bool exact_leaf_entry(const float4 q2, const float4 q3, const f3 o, const f3 inv, float &m) {
+    const float4 a = make_float4(q2.y, q2.z, q3.x, q3.y), b = make_float4(q3.z, q3.w, 0.0f, 0.0f);
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
+    const float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
+    const float t0z = (a.z - o.z) * inv.z, t1z = (b.y - o.z) * inv.z;
+    const float nearx = nx ? t1x : t0x, farx = nx ? t0x : t1x;
+    const float neary = ny ? t1y : t0y, fary = ny ? t0y : t1y;
+    const float nearz = nz ? t1z : t0z, farz = nz ? t0z : t1z;
+    m = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+    const float tmax = fminf(farz, fminf(fary, fminf(farx, __builtin_inff())));
+    return !(tmax <= m);
+}
+
+// Takes the walk at most `steps` records further from byte offset `idx` of the compact array; `note(slot)` is called for
+// every leaf record that passes.
+template <bool STATS, class N>
+RT_D void compact_walk_from(const KParams &P, const f3 inv, const GridRay g, uint32_t &idx, int steps, Cnt &cnt, N &&note) {
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const uint32_t n = P.n_fnodes * 16u;
+    uint32_t at = idx;
+    while (at < n) {
+        if (steps-- == 0)
+            break;
+        const uint4 r = *(const uint4 *)((const char *)P.cnodes + at);
+        if (STATS)
+            cnt.box++;
+        const float t0x = __builtin_fmaf((float)(r.x & 0xFFFFu), g.A.x, g.B.x), t1x = __builtin_fmaf((float)(r.x >> 16), g.A.x, g.B.x);
+        const float t0y = __builtin_fmaf((float)(r.y & 0xFFFFu), g.A.y, g.B.y), t1y = __builtin_fmaf((float)(r.y >> 16), g.A.y, g.B.y);
+        const float t0z = __builtin_fmaf((float)(r.z & 0xFFFFu), g.A.z, g.B.z), t1z = __builtin_fmaf((float)(r.z >> 16), g.A.z, g.B.z);
+        const float nearx = nx ? t1x : t0x, farx = nx ? t0x : t1x;
+        const float neary = ny ? t1y : t0y, fary = ny ? t0y : t1y;
+        const float nearz = nz ? t1z : t0z, farz = nz ? t0z : t1z;
+        const float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+        const float tmax = fminf(farz, fminf(fary, fminf(farx, __builtin_inff())));
+        const bool miss = tmax <= tmin, leaf = (r.w & 1u) != 0u;
+        if (leaf && !miss)
+            note(r.w >> 4);
+        at = (miss && !leaf) ? r.w : at + 16u;
+    }
+    idx = at;
+}
+
+// resolve_jobs for the compact walk: a job is a leaf whose grid box the owner's ray met; it runs the leaf's exact box test
+// and, if that passes, the triangle test.  `o`, `d`, `inv`: this lane's own ray.
+template <bool STATS>
+RT_D void resolve_jobs_compact(const KParams &P, const uint32_t lane, const f3 o, const f3 d, const f3 inv, WaveJobs &J, Cnt &cnt) {
+    const float inf = __builtin_inff();
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t noted = J.count;
+    const uint32_t n_jobs = noted < kJobCap ? noted : kJobCap;
+    for (uint32_t base = 0; base < n_jobs; base += 64u) {
+        const uint32_t j = base + lane;
+        const bool valid = j < n_jobs;
+        const uint2 job = valid ? J.jobs[j] : make_uint2(0u, 0u);
+        const uint32_t owner = job.x >> kJobSlotBits, slot = job.x & (kJobSphere - 1u);
+        const int sel = (int)(owner << 2);
+        const f3 ro = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.x))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.y))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.z))));
+        const f3 rd = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.x))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.y))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.z))));
+        const f3 ri = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.x))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.y))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.z))));
+        bool hit = false;
+        unsigned long long key = ~0ull;
+        float hu = 0.0f, hv = 0.0f, ht = 0.0f, hm = 0.0f;
+        if (valid) {
+            // one 64-byte record holds the leaf's box and its triangle: a single round trip to memory per pass
+            const float4 q0 = P.leaf_boxes[4 * slot], q1 = P.leaf_boxes[4 * slot + 1], q2 = P.leaf_boxes[4 * slot + 2], q3 = P.leaf_boxes[4 * slot + 3];
+            if (STATS)
+                cnt.box++;
+            if (exact_leaf_entry(q2, q3, ro, ri, hm)) {
+                if (STATS)
+                    cnt.tri++;
+                float t, u, v;
+                // t = +inf passes "t > EPSILON" but never the reference's "t < closest.t"
+                if (tri_test(ro, rd, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), t, u, v) && t < inf) {
+                    hit = true;
+                    key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)__float_as_uint(q2.w);
+                    hu = u;
+                    hv = v;
+                    ht = t;
+                }
+            }
+        }
+        if (hit)
+            atomicMin(&J.key[owner], key);
+        __builtin_amdgcn_wave_barrier();
+        if (hit) {
+            if (J.key[owner] == key) {
+                J.win[owner] = make_float4(hu, hv, __uint_as_float(slot), hm);
+                J.win_t[owner] = ht;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0)
+        J.count = 0u;
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Merges what resolve_jobs left for this lane into the lane's own best (which holds the tests it ran on the spot).
 RT_D void take_noted_result(const bool live, const uint32_t lane, WaveJobs &J, Best &best, uint32_t &bpos, float &bm) {
     const unsigned long long mine = J.key[lane];

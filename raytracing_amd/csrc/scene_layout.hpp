@@ -7,6 +7,16 @@ struct SceneLayout {
     uint32_t n_ref = 0, n_fast = 0, n_tri_slots = 0, n_sph_slots = 0;
     double expected_visits = 0.0;
     bool nested = true; // every interior box of the caller's tree contains its children's boxes
+    // Compact form of the fast tree, flat scenes only: one 16-byte record per node -- six 16-bit planes of a box that
+    // CONTAINS the node's box with one grid unit to spare on every side, and a word: byte offset (in this array) of the
+    // first record after the subtree for an interior node, (triangle slot << 4) | 1 for a leaf -- and the leaves' exact
+    // boxes by triangle slot.  The walk over it only has to be conservative; the exact leaf test runs with the triangle test.
+    std::vector<uint4> cn;
+    std::vector<float4> lb; // 4 x float4 per triangle slot, all a leaf's tests need: p0.xyz, e1.x | e1.yz, e2.xy | e2.z, pMin.xy, pos | pMin.z, pMax.xyz
+    float q_origin[3] = {0, 0, 0}, q_step[3] = {1, 1, 1};
+    bool compact = false;
+    double fast_visits = 0.0; // surface area of all fast-tree boxes / the root's: records a random ray through the root box meets
+    double compact_inflation = 1.0; // surface area of all grid boxes / surface area of all exact boxes (visits of a random ray)
 };
 
 int lfail(std::string &err, int code, const std::string &msg) {
@@ -250,6 +260,88 @@ int build_layout(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt
             sum += area(nodes[order_of[p]]);
         const double ra = area(nodes[root]);
         L.expected_visits = ra > 0.0 ? sum / ra : (double)m;
+    }
+    // 6. The compact form of the fast tree (see SceneLayout::cn).
+    L.compact = false;
+    if (n_spheres == 0 && mesh_trees.empty() && n_fast > 0 && tri_slots < (1u << 28)) {
+        const float4 ra = fn[0], rb = fn[1];
+        const double lo[3] = {ra.x, ra.y, ra.z}, hi[3] = {ra.w, rb.x, rb.y};
+        bool ok = true;
+        double ext_max = 0.0;
+        for (int k = 0; k < 3; k++)
+            ext_max = hi[k] - lo[k] > ext_max ? hi[k] - lo[k] : ext_max;
+        for (int k = 0; k < 3; k++) {
+            double ext = hi[k] - lo[k];
+            if (!(ext >= 0.0) || !(ext < 1e30))
+                ok = false;
+            // A thin scene keeps a grid of at least an eighth of its largest extent on every axis: the grid arithmetic's
+            // error grows with the distance of a ray's origin in grid extents, and a camera stands off a flat scene by the
+            // scene's size, not its thickness.
+            if (ext < ext_max / 8.0)
+                ext = ext_max / 8.0;
+            float step = (float)(ext / 65530.0);
+            if (!(step > 1e-30f))
+                step = 1e-30f;
+            L.q_step[k] = step;
+            L.q_origin[k] = (float)(lo[k] - 2.0 * (double)step);
+        }
+        if (ok) {
+            L.cn.resize(n_fast);
+            L.lb.assign(4 * (size_t)tri_slots, make_float4(0.f, 0.f, 0.f, 0.f));
+            auto qlo = [&](double p, int k) {
+                double q = std::floor((p - (double)L.q_origin[k]) / (double)L.q_step[k]) - 1.0;
+                return (uint32_t)(q < 0.0 ? 0.0 : q > 65535.0 ? 65535.0 : q);
+            };
+            auto qhi = [&](double p, int k) {
+                double q = std::ceil((p - (double)L.q_origin[k]) / (double)L.q_step[k]) + 1.0;
+                return (uint32_t)(q < 0.0 ? 0.0 : q > 65535.0 ? 65535.0 : q);
+            };
+            double area_q = 0.0, area_x = 0.0;
+            for (uint32_t i = 0; i < n_fast && ok; i++) {
+                const float4 a = fn[2 * (size_t)i], b = fn[2 * (size_t)i + 1];
+                const double bl[3] = {a.x, a.y, a.z}, bh[3] = {a.w, b.x, b.y};
+                uint32_t q[6];
+                for (int k = 0; k < 3; k++) {
+                    q[k] = qlo(bl[k], k);
+                    q[3 + k] = qhi(bh[k], k);
+                    // the grid planes must enclose the box with a unit to spare (they do unless a coordinate is not finite)
+                    if (!((double)L.q_origin[k] + q[k] * (double)L.q_step[k] <= bl[k] - 0.5 * (double)L.q_step[k]) ||
+                        !((double)L.q_origin[k] + q[3 + k] * (double)L.q_step[k] >= bh[k] + 0.5 * (double)L.q_step[k]))
+                        ok = false;
+                }
+                uint32_t skip_w, word_w;
+                std::memcpy(&skip_w, &b.z, 4);
+                std::memcpy(&word_w, &b.w, 4);
+                uint32_t w;
+                if ((word_w & 7u) == KIND_TRI) {
+                    const uint32_t slot = word_w >> 3;
+                    w = (slot << 4) | 1u;
+                    const float4 t0 = tp[3 * (size_t)slot], t1 = tp[3 * (size_t)slot + 1], t2 = tp[3 * (size_t)slot + 2];
+                    L.lb[4 * (size_t)slot] = t0;
+                    L.lb[4 * (size_t)slot + 1] = t1;
+                    L.lb[4 * (size_t)slot + 2] = make_float4(t2.x, a.x, a.y, t2.w);
+                    L.lb[4 * (size_t)slot + 3] = make_float4(a.z, a.w, b.x, b.y);
+                } else {
+                    w = (skip_w / 32u) * 16u;
+                }
+                L.cn[i] = make_uint4(q[0] | (q[3] << 16), q[1] | (q[4] << 16), q[2] | (q[5] << 16), w);
+                const double ex[3] = {bh[0] - bl[0], bh[1] - bl[1], bh[2] - bl[2]};
+                const double eq[3] = {(double)(q[3] - q[0]) * L.q_step[0], (double)(q[4] - q[1]) * L.q_step[1], (double)(q[5] - q[2]) * L.q_step[2]};
+                area_x += ex[0] * ex[1] + ex[1] * ex[2] + ex[2] * ex[0];
+                area_q += eq[0] * eq[1] + eq[1] * eq[2] + eq[2] * eq[0];
+            }
+            {
+                const double rx[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+                const double root_area = rx[0] * rx[1] + rx[1] * rx[2] + rx[2] * rx[0];
+                L.fast_visits = root_area > 0.0 ? area_x / root_area : (double)n_fast;
+            }
+            L.compact = ok;
+            L.compact_inflation = area_x > 0.0 ? area_q / area_x : 1e30;
+            if (!ok) {
+                L.cn.clear();
+                L.lb.clear();
+            }
+        }
     }
     L.n_ref = m;
     L.n_fast = n_fast;
