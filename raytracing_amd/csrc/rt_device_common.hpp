@@ -42,7 +42,7 @@ struct KParams {
     const uint4 *cnodes;       // compact fast tree (flat scenes): 16 bytes per node, see SceneLayout::cn
     const float4 *leaf_boxes;  // ... and its leaves: triangle and exact box, 4 x float4 per triangle slot
     f3 q_origin, q_step;       // ... and the grid its 16-bit planes live on
-    int compact;               // the sliced / re-fill walks go over the compact tree
+    int compact;               // the sliced / re-fill walks go over the compact tree (2: two records per trip to memory)
     int refill_tail;           // k_sliced leaves a round of at most tail_rays rays to the re-fill kernel launched before it
     const float4 *tri_pos; // 3 x float4 per triangle slot: p0, e1, e2, prim id, material
     const float4 *tri_nrm; // 3 x float4 per triangle slot: n0, n1, n2

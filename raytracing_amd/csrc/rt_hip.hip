@@ -492,7 +492,7 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
         if (!(rel > -32.0f * ext && rel < 33.0f * ext))
             pl.compact = false;
     }
-    P.compact = pl.compact ? 1 : 0;
+    P.compact = !pl.compact ? 0 : ctx->scene_bytes > kRefillSceneBytes ? 2 : 1; // 2: two records per trip to memory
     P.npix = (uint32_t)pl.npix;
     pl.W = W;
     pl.H = H;
@@ -598,13 +598,16 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
         // fetch latency; the spills land in the shading code, which runs once per ray); the others: uncapped
 #define RT_LAUNCH_PATH(OLD_, STATS_)                                                                                  \
     do {                                                                                                              \
-        if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail && !OLD_ && pl.compact) hipLaunchKernelGGL((k_refill<false, STATS_, true, true>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail) hipLaunchKernelGGL((k_refill<OLD_, STATS_, false, true>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST && sliced && !OLD_ && pl.compact) hipLaunchKernelGGL((k_sliced<false, STATS_, true>), grid, block, 0, stream, P); \
+        if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail && !OLD_ && P.compact == 2) hipLaunchKernelGGL((k_refill<false, STATS_, 2, true>), grid, block, 0, stream, P); \
+        else if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail && !OLD_ && P.compact == 1) hipLaunchKernelGGL((k_refill<false, STATS_, 1, true>), grid, block, 0, stream, P); \
+        else if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail) hipLaunchKernelGGL((k_refill<OLD_, STATS_, 0, true>), grid, block, 0, stream, P); \
+        else if (walk == WALK_FAST && sliced && !OLD_ && P.compact == 2) hipLaunchKernelGGL((k_sliced<false, STATS_, 2>), grid, block, 0, stream, P); \
+        else if (walk == WALK_FAST && sliced && !OLD_ && P.compact == 1) hipLaunchKernelGGL((k_sliced<false, STATS_, 1>), grid, block, 0, stream, P); \
         else if (walk == WALK_FAST && sliced) hipLaunchKernelGGL((k_sliced<OLD_, STATS_>), grid, block, 0, stream, P); \
         else if (walk == WALK_FAST && queued) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_QUEUED>), grid, block, 0, stream, P); \
         else if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST && refill && !OLD_ && pl.compact) hipLaunchKernelGGL((k_refill<false, STATS_, true>), grid, block, 0, stream, P); \
+        else if (walk == WALK_FAST && refill && !OLD_ && P.compact == 2) hipLaunchKernelGGL((k_refill<false, STATS_, 2>), grid, block, 0, stream, P); \
+        else if (walk == WALK_FAST && refill && !OLD_ && P.compact == 1) hipLaunchKernelGGL((k_refill<false, STATS_, 1>), grid, block, 0, stream, P); \
         else if (walk == WALK_FAST && refill) hipLaunchKernelGGL((k_refill<OLD_, STATS_>), grid, block, 0, stream, P); \
         else if (walk == WALK_FAST) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_FAST>), grid, block, 0, stream, P); \
         else if (walk == WALK_BRUTE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_BRUTE>), grid, block, 0, stream, P); \
@@ -616,15 +619,17 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
             P.refill_tail = 1;
             switch (pl.variant) {
             case 4:
-                if (pl.compact) hipLaunchKernelGGL((k_refill<false, false, true, true>), grid, block, 0, stream, P);
-                else hipLaunchKernelGGL((k_refill<false, false, false, true>), grid, block, 0, stream, P);
+                if (P.compact == 2) hipLaunchKernelGGL((k_refill<false, false, 2, true>), grid, block, 0, stream, P);
+                else if (P.compact == 1) hipLaunchKernelGGL((k_refill<false, false, 1, true>), grid, block, 0, stream, P);
+                else hipLaunchKernelGGL((k_refill<false, false, 0, true>), grid, block, 0, stream, P);
                 break;
             case 5:
-                if (pl.compact) hipLaunchKernelGGL((k_refill<false, true, true, true>), grid, block, 0, stream, P);
-                else hipLaunchKernelGGL((k_refill<false, true, false, true>), grid, block, 0, stream, P);
+                if (P.compact == 2) hipLaunchKernelGGL((k_refill<false, true, 2, true>), grid, block, 0, stream, P);
+                else if (P.compact == 1) hipLaunchKernelGGL((k_refill<false, true, 1, true>), grid, block, 0, stream, P);
+                else hipLaunchKernelGGL((k_refill<false, true, 0, true>), grid, block, 0, stream, P);
                 break;
-            case 6: hipLaunchKernelGGL((k_refill<true, false, false, true>), grid, block, 0, stream, P); break;
-            default: hipLaunchKernelGGL((k_refill<true, true, false, true>), grid, block, 0, stream, P); break;
+            case 6: hipLaunchKernelGGL((k_refill<true, false, 0, true>), grid, block, 0, stream, P); break;
+            default: hipLaunchKernelGGL((k_refill<true, true, 0, true>), grid, block, 0, stream, P); break;
             }
             RT_HIP_CHECK(ctx, hipGetLastError());
         } else {

@@ -524,7 +524,7 @@ constexpr size_t kRefillSceneBytes = 32u << 20; // 8 XCDs x 4 MB of L2
 
 // WALKS = true: the kernel finishes a round of k_sliced -- its queue holds that kernel's six-float4 records, rays in the
 // middle of their walks among them -- and follows every path to its end (tail mode).
-template <bool OLD, bool STATS, bool COMPACT = false, bool WALKS = false>
+template <bool OLD, bool STATS, int COMPACT = 0, bool WALKS = false>
 __global__ void __launch_bounds__(256) k_refill(const KParams P) {
     constexpr size_t R4 = WALKS ? 6 : 4; // float4 per queue record
     const uint32_t lane = threadIdx.x & 63u;
@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
         // ---- walk in bursts until enough lanes wait for service ----
         for (;;) {
             if (COMPACT && has && w.idx < n) {
-                compact_walk_from<STATS>(P, path.inv, grid, w.idx, kBurst, cnt,
+                compact_walk_from<STATS, COMPACT == 2>(P, path.inv, grid, w.idx, kBurst, cnt,
                                          [&](const uint32_t slot) { note_leaf<STATS>(P, lane, slot, path, J, best, bpos, bm, cnt); });
             } else if (has && w.idx < n) {
                 fast_walk_from<OLD, STATS, kBurst>(P, path.o, path.d, path.inv, w, cnt, [&](const Cand &c) {
@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
 // end of the slice (WaveJobs), so that the dense walk is not interrupted for the few lanes that stand on a leaf.  A round
 // whose queue cannot fill the chip finishes everything in place (tail mode, as k_path).  Records are six float4: the
 // four of k_path plus the walk.  Same per-ray arithmetic as k_path, same results.
-template <bool OLD, bool STATS, bool COMPACT = false>
+template <bool OLD, bool STATS, int COMPACT = 0>
 __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -876,7 +876,7 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
                 grid = grid_ray(P, path.o, path.inv);
             for (int left = slice;;) {
                 if (COMPACT && live && w.idx < n) {
-                    compact_walk_from<STATS>(P, path.inv, grid, w.idx, left < kSliceBurst ? left : kSliceBurst, cnt,
+                    compact_walk_from<STATS, COMPACT == 2>(P, path.inv, grid, w.idx, left < kSliceBurst ? left : kSliceBurst, cnt,
                                              [&](const uint32_t slot) { note_leaf<STATS>(P, lane, slot, path, J, best, bpos, bm, cnt); });
                 } else if (live && w.idx < n) {
                     w.slice = left < kSliceBurst ? left : kSliceBurst;

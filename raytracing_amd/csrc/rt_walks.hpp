@@ -746,31 +746,66 @@ RT_D bool exact_leaf_entry(const float4 q2, const float4 q3, const f3 o, const f
     return !(tmax <= m);
 }
 
-// Takes the walk at most `steps` records further from byte offset `idx` of the compact array; `note(slot)` is called for
-// every leaf record that passes.
-template <bool STATS, class N>
+// Takes the walk about `steps` records further from byte offset `idx` of the compact array; `note(slot)` is called for
+// every leaf record that passes.  PAIR (scenes beyond the L2s, where a trip to memory is long; KParams::compact == 2): every trip
+// brings the record the walk stands on AND the one behind it (the same 128-byte line seven times out of eight): after a
+// record that does not prune -- an interior box that is met, or any leaf -- the walk's next record is that one, and it is
+// tested at once; only a pruned subtree costs a trip for a single record (measured: 6 to 10 % faster on the 101 and 133 MB
+// scenes, 2 % slower on scenes within the L2s).  The array ends with one unused record, so the second load never leaves it.
+// One record of the compact walk: the slab test on its grid planes; true when the ray misses the box.
+RT_D bool grid_box_missed(const uint4 r, const GridRay &g, const bool nx, const bool ny, const bool nz) {
+    const float t0x = __builtin_fmaf((float)(r.x & 0xFFFFu), g.A.x, g.B.x), t1x = __builtin_fmaf((float)(r.x >> 16), g.A.x, g.B.x);
+    const float t0y = __builtin_fmaf((float)(r.y & 0xFFFFu), g.A.y, g.B.y), t1y = __builtin_fmaf((float)(r.y >> 16), g.A.y, g.B.y);
+    const float t0z = __builtin_fmaf((float)(r.z & 0xFFFFu), g.A.z, g.B.z), t1z = __builtin_fmaf((float)(r.z >> 16), g.A.z, g.B.z);
+    const float nearx = nx ? t1x : t0x, farx = nx ? t0x : t1x;
+    const float neary = ny ? t1y : t0y, fary = ny ? t0y : t1y;
+    const float nearz = nz ? t1z : t0z, farz = nz ? t0z : t1z;
+    const float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+    const float tmax = fminf(farz, fminf(fary, fminf(farx, __builtin_inff())));
+    return tmax <= tmin;
+}
+
+template <bool STATS, bool PAIR, class N>
 RT_D void compact_walk_from(const KParams &P, const f3 inv, const GridRay g, uint32_t &idx, int steps, Cnt &cnt, N &&note) {
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     const uint32_t n = P.n_fnodes * 16u;
     uint32_t at = idx;
-    while (at < n) {
-        if (steps-- == 0)
-            break;
-        const uint4 r = *(const uint4 *)((const char *)P.cnodes + at);
-        if (STATS)
-            cnt.box++;
-        const float t0x = __builtin_fmaf((float)(r.x & 0xFFFFu), g.A.x, g.B.x), t1x = __builtin_fmaf((float)(r.x >> 16), g.A.x, g.B.x);
-        const float t0y = __builtin_fmaf((float)(r.y & 0xFFFFu), g.A.y, g.B.y), t1y = __builtin_fmaf((float)(r.y >> 16), g.A.y, g.B.y);
-        const float t0z = __builtin_fmaf((float)(r.z & 0xFFFFu), g.A.z, g.B.z), t1z = __builtin_fmaf((float)(r.z >> 16), g.A.z, g.B.z);
-        const float nearx = nx ? t1x : t0x, farx = nx ? t0x : t1x;
-        const float neary = ny ? t1y : t0y, fary = ny ? t0y : t1y;
-        const float nearz = nz ? t1z : t0z, farz = nz ? t0z : t1z;
-        const float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
-        const float tmax = fminf(farz, fminf(fary, fminf(farx, __builtin_inff())));
-        const bool miss = tmax <= tmin, leaf = (r.w & 1u) != 0u;
-        if (leaf && !miss)
-            note(r.w >> 4);
-        at = (miss && !leaf) ? r.w : at + 16u;
+    if constexpr (!PAIR) {
+        while (at < n) {
+            if (steps-- == 0)
+                break;
+            const uint4 r = *(const uint4 *)((const char *)P.cnodes + at);
+            if (STATS)
+                cnt.box++;
+            const bool miss = grid_box_missed(r, g, nx, ny, nz), leaf = (r.w & 1u) != 0u;
+            if (leaf && !miss)
+                note(r.w >> 4);
+            at = (miss && !leaf) ? r.w : at + 16u;
+        }
+    } else {
+        while (at < n) {
+            if (steps <= 0)
+                break;
+            steps -= 2;
+            uint4 r = *(const uint4 *)((const char *)P.cnodes + at);
+            const uint4 r1 = *(const uint4 *)((const char *)P.cnodes + at + 16u);
+#pragma unroll 1
+            for (int k = 0; k < 2; k++) {
+                if (STATS)
+                    cnt.box++;
+                const bool miss = grid_box_missed(r, g, nx, ny, nz), leaf = (r.w & 1u) != 0u;
+                if (leaf && !miss)
+                    note(r.w >> 4);
+                if (miss && !leaf) {
+                    at = r.w;
+                    break;
+                }
+                at += 16u;
+                if (!(at < n))
+                    break;
+                r = r1;
+            }
+        }
     }
     idx = at;
 }

@@ -286,7 +286,7 @@ int build_layout(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt
             L.q_origin[k] = (float)(lo[k] - 2.0 * (double)step);
         }
         if (ok) {
-            L.cn.resize(n_fast);
+            L.cn.assign((size_t)n_fast + 1, make_uint4(0u, 0u, 0u, 0u)); // one unused record at the end: the walk loads records in twos
             L.lb.assign(4 * (size_t)tri_slots, make_float4(0.f, 0.f, 0.f, 0.f));
             auto qlo = [&](double p, int k) {
                 double q = std::floor((p - (double)L.q_origin[k]) / (double)L.q_step[k]) - 1.0;
