@@ -29,6 +29,7 @@ constexpr int kCounterSlots = 64, kCounterStride = 16; // statistics are added i
 constexpr int kMaxLevels = 64;             // bounce levels a wavefront trace can launch (bounce_limit <= 62)
 constexpr uint32_t kTailRays = 256u << 10;  // a level with no more rays than this follows every path to its end in one launch
 constexpr uint32_t kSlice = 128;            // k_sliced: records a ray is taken further per round
+constexpr uint32_t kSliceShort = 64;       // ... in scenes whose walks are short
 constexpr int kSliceBurst = 32;            // k_sliced: records between two looks at the wave's list of noted tests
 constexpr int kSliceExtraRounds = 0;       // k_sliced: launches beyond one per bounce level (the last one finishes whatever is left)
 constexpr uint32_t kSliceTailRays = 2u << 20; // k_sliced: a round with no more rays than this is finished by the re-fill kernel

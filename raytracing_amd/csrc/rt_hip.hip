@@ -101,6 +101,7 @@ struct rt_ctx {
     float q_origin[3] = {0, 0, 0}, q_step[3] = {1, 1, 1};
     bool has_compact = false;
     double compact_inflation = 1.0;
+    double fast_visits = 0.0; // fast-tree records a random ray through the root box meets (flat scenes; 0: not computed)
     bool has_scene = false;
     size_t scene_bytes = 0; // fast-tree records + triangle positions
     bool fast_exact = true; // the uploaded tree's interior boxes contain their children's (see build_layout)
@@ -230,6 +231,7 @@ void free_scene(rt_ctx *c) {
     if (c->d_leaf_boxes) (void)hipFree(c->d_leaf_boxes);
     c->d_cnodes = c->d_leaf_boxes = nullptr;
     c->has_compact = false;
+    c->fast_visits = 0.0;
     c->d_nodes = c->d_tri_pos = c->d_tri_nrm = c->d_spheres = c->d_mats = nullptr;
     c->n_nodes = 0;
     c->has_scene = false;
@@ -301,7 +303,7 @@ int sync_all(rt_ctx *ctx) {
 // The tracer's tuning constants; each can be overridden from the environment for measurements (RT_SLICE, RT_TAIL_RAYS,
 // RT_EXTRA_ROUNDS, RT_CHUNK_SAMPLES), read once per process.  Results do not depend on them.
 struct Tuning {
-    uint32_t slice = kSlice, tail_rays = kTailRays, slice_tail_rays = kSliceTailRays;
+    uint32_t slice = 0, tail_rays = kTailRays, slice_tail_rays = kSliceTailRays;
     int extra_rounds = kSliceExtraRounds, chunk_samples = kChunkSamples;
     int compact = 1; // RT_COMPACT=0: no walk takes the compact tree; 2: traces that collect statistics take it too
     int refill_tail = 1; // RT_REFILL_TAIL=0: k_sliced finishes its last round itself
@@ -316,7 +318,7 @@ const Tuning &tuning() {
             const long x = std::strtol(e, nullptr, 10);
             return x < lo ? lo : x > hi ? hi : x;
         };
-        v.slice = (uint32_t)env("RT_SLICE", 1, 1 << 20, kSlice);
+        v.slice = (uint32_t)env("RT_SLICE", 1, 1 << 20, 0); // 0: chosen per scene (make_plan)
         v.tail_rays = (uint32_t)env("RT_TAIL_RAYS", 0, 1 << 30, kTailRays);
         v.slice_tail_rays = (uint32_t)env("RT_TAIL_RAYS", 0, 1 << 30, kSliceTailRays);
         v.extra_rounds = (int)env("RT_EXTRA_ROUNDS", -32, 32, kSliceExtraRounds);
@@ -474,7 +476,11 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
         pl.camera = false;
     P.camera_stage = pl.camera ? 1 : 0;
     P.deferred = nullptr;
-    P.slice = tuning().slice;
+    // Slice length: a lane idles from the end of its walk to the end of the slice, so the slice follows the length of the
+    // scene's walks.  The measure is the number of fast-tree records a random ray through the root box meets (sum of the
+    // boxes' surface areas over the root's): 31 to 47 for the bare meshes and fields (best slice 128, of 32 ... 192 swept),
+    // 6 for the 907 k-triangle pair on its ground quad, whose root box is mostly empty (best slice 64: -8 %).
+    P.slice = tuning().slice != 0 ? tuning().slice : (ctx->fast_visits > 0.0 && ctx->fast_visits < 16.0) ? kSliceShort : kSlice;
     P.tail_rays = pl.sliced && tuning().refill_tail != 0 ? tuning().slice_tail_rays : tuning().tail_rays;
     pl.rec4 = pl.sliced ? 6 : 4;
     // Compact tree: when the scene has one and every ray of the call starts close enough to it for the grid arithmetic's
@@ -933,6 +939,7 @@ int upload_layout(rt_ctx *ctx, const SceneLayout &L) {
         std::memcpy(ctx->q_step, L.q_step, sizeof(ctx->q_step));
         ctx->has_compact = true;
         ctx->compact_inflation = L.compact_inflation;
+        ctx->fast_visits = L.fast_visits;
         if (std::getenv("RT_DEBUG_LAYOUT"))
             std::fprintf(stderr, "compact inflation %.4f expected visits %.2f fast visits %.2f scene bytes %zu\n", L.compact_inflation, L.expected_visits, L.fast_visits,
                          (L.fn.size() + L.tp.size()) * sizeof(float4));
