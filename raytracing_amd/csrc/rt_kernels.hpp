@@ -482,12 +482,12 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : (WALK == WALK_QUE
     }
 }
 
-// What a lane of the compact walk does with a leaf record that passed its grid box: the leaf goes on the wave's list
-// (resolve_jobs_compact); with no room there, its exact box test and triangle test run on the spot.
+// What a lane of the compact walk does with a leaf record that passed its grid box, once it knows its place `j` in the
+// wave's list (compact_walk_from): the leaf goes there (resolve_jobs_compact); with no room, its exact box test and
+// triangle test run on the spot.
 template <bool STATS>
-RT_D void note_leaf(const KParams &P, const uint32_t lane, const uint32_t slot, const Path &path, WaveJobs &J, Best &best, uint32_t &bpos,
-                    float &bm, Cnt &cnt) {
-    const uint32_t j = atomicAdd(&J.count, 1u);
+RT_D void note_leaf(const KParams &P, const uint32_t lane, const uint32_t j, const uint32_t slot, const Path &path, WaveJobs &J, Best &best,
+                    uint32_t &bpos, float &bm, Cnt &cnt) {
     if (j < kJobCap && slot < kJobSphere) {
         J.jobs[j] = make_uint2((lane << kJobSlotBits) | slot, 0u);
         return;
@@ -660,7 +660,8 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
         for (;;) {
             if (COMPACT && has && w.idx < n) {
                 compact_walk_from<STATS, COMPACT == 2>(P, path.inv, grid, w.idx, kBurst, cnt,
-                                         [&](const uint32_t slot) { note_leaf<STATS>(P, lane, slot, path, J, best, bpos, bm, cnt); });
+                                         [&]() { return atomicAdd(&J.count, 1u); },
+                                         [&](const uint32_t j, const uint32_t slot) { note_leaf<STATS>(P, lane, j, slot, path, J, best, bpos, bm, cnt); });
             } else if (has && w.idx < n) {
                 fast_walk_from<OLD, STATS, kBurst>(P, path.o, path.d, path.inv, w, cnt, [&](const Cand &c) {
                     if ((c.t < best.t || (c.t == best.t && c.pos < bpos)) && c.t < __builtin_inff()) {
@@ -877,7 +878,8 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
             for (int left = slice;;) {
                 if (COMPACT && live && w.idx < n) {
                     compact_walk_from<STATS, COMPACT == 2>(P, path.inv, grid, w.idx, left < kSliceBurst ? left : kSliceBurst, cnt,
-                                             [&](const uint32_t slot) { note_leaf<STATS>(P, lane, slot, path, J, best, bpos, bm, cnt); });
+                                             [&]() { return atomicAdd(&J.count, 1u); },
+                                         [&](const uint32_t j, const uint32_t slot) { note_leaf<STATS>(P, lane, j, slot, path, J, best, bpos, bm, cnt); });
                 } else if (live && w.idx < n) {
                     w.slice = left < kSliceBurst ? left : kSliceBurst;
                     fast_walk_from<OLD, STATS, -1>(P, path.o, path.d, path.inv, w, cnt, [&](const Cand &c) {

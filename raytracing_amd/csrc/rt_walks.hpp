@@ -765,21 +765,32 @@ RT_D bool grid_box_missed(const uint4 r, const GridRay &g, const bool nx, const 
     return tmax <= tmin;
 }
 
-template <bool STATS, bool PAIR, class N>
-RT_D void compact_walk_from(const KParams &P, const f3 inv, const GridRay g, uint32_t &idx, int steps, Cnt &cnt, N &&note) {
+// A leaf that passes is noted in two halves: `issue()` reserves a place in the wave's list (an LDS atomic whose answer
+// takes a hundred cycles), `commit(place, slot)` writes the job there.  The commit waits until the walk's NEXT record has
+// been asked for, so the atomic's latency runs under the memory latency every step pays anyway instead of adding to it
+// (nearly every step of a wave has some lane on a leaf).
+template <bool STATS, bool PAIR, class I, class C>
+RT_D void compact_walk_from(const KParams &P, const f3 inv, const GridRay g, uint32_t &idx, int steps, Cnt &cnt, I &&issue, C &&commit) {
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     const uint32_t n = P.n_fnodes * 16u;
     uint32_t at = idx;
+    uint32_t place = 0u, pending = kNone; // the leaf slot whose place has been asked for, kNone: none
     if constexpr (!PAIR) {
         while (at < n) {
             if (steps-- == 0)
                 break;
             const uint4 r = *(const uint4 *)((const char *)P.cnodes + at);
+            if (pending != kNone) {
+                commit(place, pending);
+                pending = kNone;
+            }
             if (STATS)
                 cnt.box++;
             const bool miss = grid_box_missed(r, g, nx, ny, nz), leaf = (r.w & 1u) != 0u;
-            if (leaf && !miss)
-                note(r.w >> 4);
+            if (leaf && !miss) {
+                place = issue();
+                pending = r.w >> 4;
+            }
             at = (miss && !leaf) ? r.w : at + 16u;
         }
     } else {
@@ -789,13 +800,21 @@ RT_D void compact_walk_from(const KParams &P, const f3 inv, const GridRay g, uin
             steps -= 2;
             uint4 r = *(const uint4 *)((const char *)P.cnodes + at);
             const uint4 r1 = *(const uint4 *)((const char *)P.cnodes + at + 16u);
+            if (pending != kNone) {
+                commit(place, pending);
+                pending = kNone;
+            }
 #pragma unroll 1
             for (int k = 0; k < 2; k++) {
                 if (STATS)
                     cnt.box++;
                 const bool miss = grid_box_missed(r, g, nx, ny, nz), leaf = (r.w & 1u) != 0u;
-                if (leaf && !miss)
-                    note(r.w >> 4);
+                if (leaf && !miss) {
+                    if (pending != kNone)
+                        commit(place, pending);
+                    place = issue();
+                    pending = r.w >> 4;
+                }
                 if (miss && !leaf) {
                     at = r.w;
                     break;
@@ -807,6 +826,8 @@ RT_D void compact_walk_from(const KParams &P, const f3 inv, const GridRay g, uin
             }
         }
     }
+    if (pending != kNone)
+        commit(place, pending);
     idx = at;
 }
 
