@@ -442,11 +442,15 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
         trav = ctx->expected_visits >= 512.0 ? RT_TRAV_WAVE : RT_TRAV_LANE;
     P.force_replay = trav == RT_TRAV_FAST_REPLAY ? 1 : 0;
     // RT_TRAV_FAST: the loop estimator's scenes are walked in slices, rounds that no longer fill the chip finished with lane
-    // re-fill (measured against re-fill alone: level on the 907 k-triangle pair, 10 to 20 % ahead on the other scenes,
-    // small and large).  The recursive estimator's scenes (spheres, mesh objects): lane re-fill when the fast tree and
-    // triangle positions exceed the L2s, k_path with the noted primitive tests otherwise.
-    pl.refill = trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && old && ctx->scene_bytes > kRefillSceneBytes);
-    pl.sliced = trav == RT_TRAV_FAST_SLICED || (trav == RT_TRAV_FAST && !old);
+    // re-fill -- slices bound what the longest walks cost, and against re-fill alone that is 5 to 25 % faster on the bare
+    // meshes and the fields (31 to 47 records met by a random ray through the root box, see fast_visits) -- unless the
+    // scene's walks are short (4 to 6 records: a mesh on a ground quad many times its size), where there is nothing to
+    // bound and re-fill alone is level (18 520 triangles) to 5 % ahead (907 k triangles, 64-sample chunks).  The recursive
+    // estimator's scenes (spheres, mesh objects): lane re-fill when the fast tree and triangle positions exceed the L2s,
+    // k_path with the noted primitive tests otherwise.
+    const bool short_walks = ctx->fast_visits > 0.0 && ctx->fast_visits < 16.0;
+    pl.refill = trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && (old ? ctx->scene_bytes > kRefillSceneBytes : short_walks));
+    pl.sliced = trav == RT_TRAV_FAST_SLICED || (trav == RT_TRAV_FAST && !old && !pl.refill);
     pl.queued = trav == RT_TRAV_FAST_QUEUED || (trav == RT_TRAV_FAST && !pl.refill && !pl.sliced);
     if (trav == RT_TRAV_FAST_QUEUED || trav == RT_TRAV_FAST_INLINE || trav == RT_TRAV_FAST_SLICED || trav == RT_TRAV_FAST_REFILL)
         trav = RT_TRAV_FAST;
@@ -479,8 +483,9 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     // Slice length: a lane idles from the end of its walk to the end of the slice, so the slice follows the length of the
     // scene's walks.  The measure is the number of fast-tree records a random ray through the root box meets (sum of the
     // boxes' surface areas over the root's): 31 to 47 for the bare meshes and fields (best slice 128, of 32 ... 192 swept),
-    // 6 for the 907 k-triangle pair on its ground quad, whose root box is mostly empty (best slice 64: -8 %).
-    P.slice = tuning().slice != 0 ? tuning().slice : (ctx->fast_visits > 0.0 && ctx->fast_visits < 16.0) ? kSliceShort : kSlice;
+    // 4 to 6 for meshes on a ground quad, whose root box is mostly empty (best slice 64: -8 to -11 %; such scenes take
+    // the re-fill kernel unless the sliced walk is asked for).
+    P.slice = tuning().slice != 0 ? tuning().slice : short_walks ? kSliceShort : kSlice;
     P.tail_rays = pl.sliced && tuning().refill_tail != 0 ? tuning().slice_tail_rays : tuning().tail_rays;
     pl.rec4 = pl.sliced ? 6 : 4;
     // Compact tree: when the scene has one and every ray of the call starts close enough to it for the grid arithmetic's

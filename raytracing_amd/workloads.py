@@ -218,6 +218,9 @@ def make_workload(name):
         return sd_workload(name, dragon_pair_models(), DRAGON_PAIR_CAMERA, w, h, 256 if name.endswith("4k") else 16,
                            bench_spp=256 if name.endswith("4k") else 64,
                            description="TheStanfordDragon18520.obj + " + FULL_DRAGON_SUBSTITUTE + ", on a ground quad; every ray hits or bounces")
+    if name == "dragon18520_ground_1080p":
+        return sd_workload(name, [_load_obj_tris(DRAGON_18520), ground_quad()], DRAGON_PAIR_CAMERA, 1920, 1080, 16, bench_spp=64,
+                           description="TheStanfordDragon18520.obj on configuration 4's ground quad (a scene within the L2s in which every ray hits or bounces)")
     if name == "dragon18520_bare_4k":
         return sd_workload(name, [_load_obj_tris(DRAGON_18520)], DRAGON_18520_CAMERA, 3840, 2160, 256,
                            description="TheStanfordDragon18520.obj alone at 4K")
