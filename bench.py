@@ -236,9 +236,15 @@ def main():
         if split == "tile" and world > 1:
             my_pixels = sum(1 for k in range(((W + 7) // 8) * ((H + 7) // 8)) if k % world == rank) * 64
 
+        flat = wl.estimator == R.EST_SD_LOOP  # walked over the 16-byte grid records, leaves tested from 64-byte records
+
         def traversal_bytes(c):
-            # 32 B per slab test (box + 2 links), 36 B per triangle test (3 positions), 16 B per sphere test,
-            # 36 B of normals per traversal that ends on a triangle
+            # flat scenes: 16 B per slab test (grid box + link), 64 B per leaf test (the leaf's exact box and its
+            # triangle in one record); pointer scenes: 32 B per slab test, 36 B per triangle test (3 positions), 16 B
+            # per sphere test; both: 36 B of normals per traversal that ends on a triangle.  The counts are those of the
+            # exact walk (the statistics variant of the kernels); the grid walk makes a few per cent more slab tests.
+            if flat:
+                return 16 * c.box_tests + 64 * c.tri_tests + 36 * c.tri_hits
             return 32 * c.box_tests + 36 * c.tri_tests + 16 * c.sph_tests + 36 * c.tri_hits
 
         def traversal_ops(c):
@@ -273,11 +279,14 @@ def main():
             roof = {"bound": "hbm", "achieved": alg_bytes / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": alg_bytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(alg_bytes),
-                    "note": "bytes the walk's own tests need (32 per slab test, 36 per triangle test, 36 of normals per "
-                            "triangle hit) + the image; the scene's records (%.0f MB) exceed every cache" % (scene_bytes / 1e6)}
+                    "note": ("bytes the walk's own tests need (%s, 36 of normals per triangle hit) + the image; the scene's "
+                             "records (%.0f MB) exceed every cache"
+                             % ("16 per slab test on the grid records, 64 per leaf test" if flat
+                                else "32 per slab test, 36 per triangle test, 16 per sphere test", scene_bytes / 1e6))}
         roof["valu_frac"] = alg_ops / secs / 1e12 / VALU_PEAK_TOPS
-        roof.update({"kernel": "one step = one trace call: k_sliced (flat scenes within the L2s), k_path (pointer scenes) or "
-                               "k_refill (beyond the L2s), one launch per round / bounce level and chunk of samples, + k_fold",
+        roof.update({"kernel": "one step = one trace call: flat scenes k_camera + k_sliced for the rounds that fill the chip + "
+                               "k_refill for the rest (short-walk scenes: k_refill throughout); pointer scenes k_path, or "
+                               "k_refill beyond the L2s; one launch per round / bounce level and chunk of samples, + k_fold",
                      "kernel_ms": kernel_ms,
                      "hbm_achieved_GBps": traffic / secs / 1e9 if traffic else None,
                      "hbm_frac": traffic / secs / 1e9 / HBM_PEAK_GBS if traffic else None,

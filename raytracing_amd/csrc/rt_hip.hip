@@ -301,7 +301,8 @@ int sync_all(rt_ctx *ctx) {
 }
 
 // The tracer's tuning constants; each can be overridden from the environment for measurements (RT_SLICE, RT_TAIL_RAYS,
-// RT_EXTRA_ROUNDS, RT_CHUNK_SAMPLES), read once per process.  Results do not depend on them.
+// RT_EXTRA_ROUNDS, RT_CHUNK_SAMPLES, RT_COMPACT, RT_REFILL_TAIL), read once per process.  Results do not depend on them.
+// (RT_DEBUG_LAYOUT=1 prints what an upload measured about the scene's fast tree to stderr.)
 struct Tuning {
     uint32_t slice = 0, tail_rays = kTailRays, slice_tail_rays = kSliceTailRays;
     int extra_rounds = kSliceExtraRounds, chunk_samples = kChunkSamples;

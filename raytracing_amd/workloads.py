@@ -113,9 +113,12 @@ class Workload:
         self.models, self.spheres = models, spheres
 
     def scene_bytes(self):
-        """Fast-tree records + triangle positions as uploaded (32 B per node of a full binary tree over the primitives,
-        48 B per triangle): what the walk touches."""
+        """What the walk touches, as uploaded.  Flat scenes (the loop estimator): 16 B per grid record of a full binary
+        tree over the triangles, 64 B per leaf record (exact box + triangle).  Pointer scenes: 32 B per fast-tree
+        record, 48 B of positions per triangle."""
         prims = len(self.scene.tris()) + len(self.scene.spheres())
+        if self.estimator == EST_SD_LOOP:
+            return 16 * max(2 * prims - 1, 1) + 64 * len(self.scene.tris())
         return 32 * max(2 * prims - 1, 1) + 48 * len(self.scene.tris())
 
 
