@@ -551,14 +551,20 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
     P = pl.P;
     if (done > 0)
         P.image_in = P.image; // later chunks continue from what the chunk before them folded
-    const int first_level = pl.camera ? 1 : 0, levels = pl.levels + first_level;
+    const int first_level = pl.camera ? 1 : 0;
+    int levels = pl.levels + first_level;
+    P.n_items = (uint32_t)((size_t)s_now * pl.items_per_sample);
+    // A chunk of the sliced walk that cannot fill the chip even in its first round (no round holds more rays than the
+    // chunk has samples) is one launch of the re-fill kernel in tail mode: an interactive 1080p frame of one sample per
+    // pixel is camera stage, that launch and the fold instead of nineteen launches, sixteen of which find nothing to do.
+    if (pl.walk == WALK_FAST && pl.sliced && tuning().refill_tail != 0 && P.n_items <= P.tail_rays)
+        levels = first_level + 1;
     RT_HIP_CHECK(ctx, hipMemsetAsync(ws.levels, 0, (size_t)(levels + 1) * kSubQueues * 32 * sizeof(unsigned int), stream));
     P.colors = ws.colors;
     P.deferred = ws.deferred;
     P.S = s_now;
     P.div_per_tile = make_fastdiv(64u * (uint32_t)s_now);
     P.chunk_first = pl.first + done;
-    P.n_items = (uint32_t)((size_t)s_now * pl.items_per_sample);
     P.sub_cap = (((P.n_items + 63u) / 64u) / (uint32_t)kSubQueues + 66u) * 64u;
     const bool sliced = pl.sliced, queued = pl.queued, refill = pl.refill;
     const bool refill_tail = tuning().refill_tail != 0; // the sliced walk's last round is finished with lane re-fill
