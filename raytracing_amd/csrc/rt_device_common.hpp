@@ -29,6 +29,7 @@ constexpr int kCounterSlots = 64, kCounterStride = 16; // statistics are added i
 constexpr int kMaxLevels = 64;             // bounce levels a wavefront trace can launch (bounce_limit <= 62)
 constexpr uint32_t kTailRays = 256u << 10;  // a level with no more rays than this follows every path to its end in one launch
 constexpr uint32_t kSlice = 128;            // k_sliced: records a ray is taken further per round
+constexpr int kSliceQuorum = 16;           // k_sliced: a wave with no more walking lanes than this ends its slice (8 / 16 / 24 / 32 swept: -1 / -3.5 / -3.8 / -2.7 % on the headline)
 constexpr uint32_t kSliceShort = 64;       // ... in scenes whose walks are short
 constexpr int kSliceBurst = 32;            // k_sliced: records between two looks at the wave's list of noted tests
 constexpr int kSliceExtraRounds = 0;       // k_sliced: launches beyond one per bounce level (the last one finishes whatever is left)
@@ -44,6 +45,7 @@ struct KParams {
     const float4 *leaf_boxes;  // ... and its leaves: triangle and exact box, 4 x float4 per triangle slot
     f3 q_origin, q_step;       // ... and the grid its 16-bit planes live on
     int compact;               // the sliced / re-fill walks go over the compact tree (2: two records per trip to memory)
+    uint32_t slice_quorum;     // k_sliced: a wave with no more walking lanes than this ends its slice
     int refill_tail;           // k_sliced leaves a round of at most tail_rays rays to the re-fill kernel launched before it
     const float4 *tri_pos; // 3 x float4 per triangle slot: p0, e1, e2, prim id, material
     const float4 *tri_nrm; // 3 x float4 per triangle slot: n0, n1, n2

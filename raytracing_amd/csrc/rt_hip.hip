@@ -308,6 +308,7 @@ struct Tuning {
     int extra_rounds = kSliceExtraRounds, chunk_samples = kChunkSamples;
     int compact = 1; // RT_COMPACT=0: no walk takes the compact tree; 2: traces that collect statistics take it too
     int refill_tail = 1; // RT_REFILL_TAIL=0: k_sliced finishes its last round itself
+    int slice_quorum = kSliceQuorum; // RT_SLICE_QUORUM
 };
 const Tuning &tuning() {
     static const Tuning t = [] {
@@ -326,6 +327,7 @@ const Tuning &tuning() {
         v.chunk_samples = (int)env("RT_CHUNK_SAMPLES", 1, kChunkSamples, kChunkSamples);
         v.compact = (int)env("RT_COMPACT", 0, 2, 1);
         v.refill_tail = (int)env("RT_REFILL_TAIL", 0, 1, 1);
+        v.slice_quorum = (int)env("RT_SLICE_QUORUM", 0, 64, kSliceQuorum);
         return v;
     }();
     return t;
@@ -504,6 +506,7 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
         if (!(rel > -32.0f * ext && rel < 33.0f * ext))
             pl.compact = false;
     }
+    P.slice_quorum = (uint32_t)tuning().slice_quorum;
     P.compact = !pl.compact ? 0 : ctx->scene_bytes > kRefillSceneBytes ? 2 : 1; // 2: two records per trip to memory
     P.npix = (uint32_t)pl.npix;
     pl.W = W;

@@ -898,8 +898,13 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
                 }
                 left = left > kSliceBurst ? left - kSliceBurst : 0;
                 __builtin_amdgcn_wave_barrier();
-                if (left == 0 || __ballot(live && w.idx < n) == 0ull)
-                    break;
+                {
+                    // the slice ends early for a wave most of whose rays are done: the few that still walk go to the next
+                    // round, where they sit in full waves again, instead of keeping this one at a handful of lanes
+                    const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(live && w.idx < n));
+                    if (left == 0 || walking == 0u || (!tail && walking <= P.slice_quorum))
+                        break;
+                }
                 if (J.count > kJobCap / 2u) {
                     if (COMPACT)
                         resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt);
