@@ -30,10 +30,10 @@ constexpr int kMaxLevels = 64;             // bounce levels a wavefront trace ca
 constexpr uint32_t kTailRays = 256u << 10;  // a level with no more rays than this follows every path to its end in one launch
 constexpr uint32_t kSlice = 128;            // k_sliced: records a ray is taken further per round
 constexpr int kSliceQuorum = 16;           // k_sliced: a wave with no more walking lanes than this ends its slice (8 / 16 / 24 / 32 swept: -1 / -3.5 / -3.8 / -2.7 % on the headline)
-constexpr uint32_t kSliceShort = 64;       // ... in scenes whose walks are short
 constexpr int kSliceBurst = 32;            // k_sliced: records between two looks at the wave's list of noted tests
 constexpr int kSliceExtraRounds = 0;       // k_sliced: launches beyond one per bounce level (the last one finishes whatever is left)
-constexpr uint32_t kSliceTailRays = 2u << 20; // k_sliced: a round with no more rays than this is finished by the re-fill kernel
+constexpr uint32_t kSliceTailRays = 12u << 20;    // k_sliced: a round with no more rays than this is finished by the re-fill kernel (1 ... 32 Mi swept)
+constexpr uint32_t kSliceTailRaysBig = 24u << 20; // ... in scenes beyond the L2s
 constexpr int kChunkSamples = 64;          // samples per pixel traced per wavefront chunk
 constexpr size_t kMaxItems = 192u << 20;   // work items (pixel samples) per chunk: bounds the queue workspace
 

@@ -304,7 +304,7 @@ int sync_all(rt_ctx *ctx) {
 // RT_EXTRA_ROUNDS, RT_CHUNK_SAMPLES, RT_COMPACT, RT_REFILL_TAIL), read once per process.  Results do not depend on them.
 // (RT_DEBUG_LAYOUT=1 prints what an upload measured about the scene's fast tree to stderr.)
 struct Tuning {
-    uint32_t slice = 0, tail_rays = kTailRays, slice_tail_rays = kSliceTailRays;
+    uint32_t slice = 0, tail_rays = kTailRays, slice_tail_rays = 0; // slice, slice_tail_rays 0: chosen per scene
     int extra_rounds = kSliceExtraRounds, chunk_samples = kChunkSamples;
     int compact = 1; // RT_COMPACT=0: no walk takes the compact tree; 2: traces that collect statistics take it too
     int refill_tail = 1; // RT_REFILL_TAIL=0: k_sliced finishes its last round itself
@@ -322,7 +322,7 @@ const Tuning &tuning() {
         };
         v.slice = (uint32_t)env("RT_SLICE", 1, 1 << 20, 0); // 0: chosen per scene (make_plan)
         v.tail_rays = (uint32_t)env("RT_TAIL_RAYS", 0, 1 << 30, kTailRays);
-        v.slice_tail_rays = (uint32_t)env("RT_TAIL_RAYS", 0, 1 << 30, kSliceTailRays);
+        v.slice_tail_rays = (uint32_t)env("RT_TAIL_RAYS", 0, 1 << 30, 0);
         v.extra_rounds = (int)env("RT_EXTRA_ROUNDS", -32, 32, kSliceExtraRounds);
         v.chunk_samples = (int)env("RT_CHUNK_SAMPLES", 1, kChunkSamples, kChunkSamples);
         v.compact = (int)env("RT_COMPACT", 0, 2, 1);
@@ -444,15 +444,13 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     if (trav == RT_TRAV_REFERENCE)
         trav = ctx->expected_visits >= 512.0 ? RT_TRAV_WAVE : RT_TRAV_LANE;
     P.force_replay = trav == RT_TRAV_FAST_REPLAY ? 1 : 0;
-    // RT_TRAV_FAST: the loop estimator's scenes are walked in slices, rounds that no longer fill the chip finished with lane
-    // re-fill -- slices bound what the longest walks cost, and against re-fill alone that is 5 to 25 % faster on the bare
-    // meshes and the fields (31 to 47 records met by a random ray through the root box, see fast_visits) -- unless the
-    // scene's walks are short (4 to 6 records: a mesh on a ground quad many times its size), where there is nothing to
-    // bound and re-fill alone is level (18 520 triangles) to 5 % ahead (907 k triangles, 64-sample chunks).  The recursive
-    // estimator's scenes (spheres, mesh objects): lane re-fill when the fast tree and triangle positions exceed the L2s,
-    // k_path with the noted primitive tests otherwise.
-    const bool short_walks = ctx->fast_visits > 0.0 && ctx->fast_visits < 16.0;
-    pl.refill = trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && (old ? ctx->scene_bytes > kRefillSceneBytes : short_walks));
+    // RT_TRAV_FAST: the loop estimator's scenes are walked in slices while a round holds more rays than the re-fill kernel
+    // finishes well in one launch (P.tail_rays), then that kernel takes everything that is left: slices bound what the
+    // longest walks cost while the chip is full, lane re-fill keeps the lanes busy once it is not.  Against re-fill alone
+    // 8 to 25 % faster on every flat scene measured (bare meshes, fields, meshes on a ground quad, 18 k to 9.8 M triangles).
+    // The recursive estimator's scenes (spheres, mesh objects): lane re-fill when the fast tree and triangle positions
+    // exceed the L2s, k_path with the noted primitive tests otherwise.
+    pl.refill = trav == RT_TRAV_FAST_REFILL || (trav == RT_TRAV_FAST && old && ctx->scene_bytes > kRefillSceneBytes);
     pl.sliced = trav == RT_TRAV_FAST_SLICED || (trav == RT_TRAV_FAST && !old && !pl.refill);
     pl.queued = trav == RT_TRAV_FAST_QUEUED || (trav == RT_TRAV_FAST && !pl.refill && !pl.sliced);
     if (trav == RT_TRAV_FAST_QUEUED || trav == RT_TRAV_FAST_INLINE || trav == RT_TRAV_FAST_SLICED || trav == RT_TRAV_FAST_REFILL)
@@ -483,13 +481,15 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
         pl.camera = false;
     P.camera_stage = pl.camera ? 1 : 0;
     P.deferred = nullptr;
-    // Slice length: a lane idles from the end of its walk to the end of the slice, so the slice follows the length of the
-    // scene's walks.  The measure is the number of fast-tree records a random ray through the root box meets (sum of the
-    // boxes' surface areas over the root's): 31 to 47 for the bare meshes and fields (best slice 128, of 32 ... 192 swept),
-    // 4 to 6 for meshes on a ground quad, whose root box is mostly empty (best slice 64: -8 to -11 %; such scenes take
-    // the re-fill kernel unless the sliced walk is asked for).
-    P.slice = tuning().slice != 0 ? tuning().slice : short_walks ? kSliceShort : kSlice;
-    P.tail_rays = pl.sliced && tuning().refill_tail != 0 ? tuning().slice_tail_rays : tuning().tail_rays;
+    // Slice length: 32 ... 192 records swept on bare meshes, fields and meshes on a ground quad (128 is best or level with
+    // the best everywhere, now that a wave ends its slice when 16 or fewer of its lanes still walk).
+    P.slice = tuning().slice != 0 ? tuning().slice : kSlice;
+    // Rounds of the sliced walk that the re-fill kernel finishes: up to 12 Mi rays, 24 Mi in scenes beyond the L2s (on the
+    // 18 520-triangle dragon that is everything after the first round; the 9.8 M-triangle field gains another 5 % at 24 Mi).
+    P.tail_rays = !(pl.sliced && tuning().refill_tail != 0) ? tuning().tail_rays
+                  : tuning().slice_tail_rays != 0           ? tuning().slice_tail_rays
+                  : ctx->scene_bytes > kRefillSceneBytes    ? kSliceTailRaysBig
+                                                            : kSliceTailRays;
     pl.rec4 = pl.sliced ? 6 : 4;
     // Compact tree: when the scene has one and every ray of the call starts close enough to it for the grid arithmetic's
     // margin (compact_walk_from): bounce rays start on the geometry, the camera within 32 grid extents per axis.
