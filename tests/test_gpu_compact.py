@@ -4,7 +4,9 @@ counts, replays -- on a bare mesh, on a mesh over a ground quad a hundred times 
 the ground straight up run along a coordinate axis), on a scene of no thickness, from cameras inside and outside the
 range the grid arithmetic is good for, over chunked calls and tile shares, and through the forced sliced / re-fill kernels.
 One case runs in a child process that makes the statistics kernels take the compact walk too, to see that it is the
-compact walk that ran: more box tests, the same triangle tests and hits."""
+compact walk that ran: more box tests, the same triangle tests and hits.  Another runs the same render under tuning
+settings far from the defaults (slice length, hand-over threshold, quorum, chunk size, extra rounds, each kernel of the
+sliced walk finishing its own rounds): how the work is cut into launches must not show in the image."""
 import os
 import subprocess
 import sys
@@ -134,3 +136,38 @@ def test_statistics_of_the_compact_walk_itself():
         trav, rays, box, tri, hits, replays, sha = exact
         assert compact[0] == trav and compact[1] == rays and compact[3:] == [tri, hits, replays, sha]
         assert int(box) < int(compact[2]) < 1.5 * int(box)      # grid boxes are looser, and each leaf's exact test is counted too
+
+
+TUNED = r"""
+import hashlib, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import raytracing_amd as R
+from raytracing_amd import workloads as WL
+t = R.Tracer(0)
+sc = R.SdScene()
+sc.add_model(WL._load_obj_tris(WL.DRAGON_2426))
+sc.add_model(WL.ground_quad(y=0.0, x0=-2.0, x1=2.0, z0=-2.0, z1=2.0))
+t.upload(sc.finalize())
+t.set_camera(R.Camera(1.0, (0.05, 0.22, 0.45), 2.0, 16.0 / 9.0, (-0.006, 0.06, -0.014)))
+for trav in (R.TRAV_AUTO, R.TRAV_FAST_REFILL):
+    t.set_options(bounce_limit=8, seed=9, traversal=trav)
+    img, prim, st = t.trace(480, 270, 1, 40, want_primary=True)
+    print(trav, st.rays, st.replays, hashlib.sha256(img.tobytes()).hexdigest(), hashlib.sha256(prim.tobytes()).hexdigest())
+"""
+
+
+def test_results_do_not_depend_on_the_tuning():
+    settings = [{},
+                {"RT_SLICE": "7", "RT_TAIL_RAYS": "3000", "RT_SLICE_QUORUM": "40", "RT_CHUNK_SAMPLES": "13"},
+                {"RT_SLICE": "1000", "RT_TAIL_RAYS": "100000000", "RT_SLICE_QUORUM": "0", "RT_EXTRA_ROUNDS": "5"},
+                {"RT_REFILL_TAIL": "0", "RT_SLICE": "33", "RT_TAIL_RAYS": "50000", "RT_CHUNK_SAMPLES": "64", "RT_EXTRA_ROUNDS": "-3"},
+                {"RT_COMPACT": "0", "RT_TAIL_RAYS": "1", "RT_SLICE_QUORUM": "63"}]
+    outs = []
+    for env in settings:
+        r = subprocess.run([sys.executable, "-c", TUNED, ROOT], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (env, r.stderr[-2000:])
+        outs.append(r.stdout.strip().splitlines())
+    assert len(outs[0]) == 2
+    for env, out in zip(settings[1:], outs[1:]):
+        assert out == outs[0], env
