@@ -292,13 +292,24 @@ int rt_sync(rt_ctx *ctx, rt_stats *stats);
  * leaf, whose own tree follows inline.  Reference-order tree: word = (slot << 3) | kind, and one terminator record
  * follows the last node.  tri_pos: 12 floats per slot = p0, e1, e2, triangle index, material, reference position
  * of the leaf (last three as uint32 bits), in fast-tree leaf order.  spheres: 8 floats per slot = centre, radius,
- * material, primitive id, dielectric flag, reference position. */
+ * material, primitive id, dielectric flag, reference position.
+ * Flat scenes (triangles only, every one a leaf of the scene's tree) also get the grid records that traces without
+ * statistics walk, one per fast-tree record and in the same order: four uint32 = x planes (low | high << 16), y planes,
+ * z planes -- plane q of an axis lies at grid_origin + q * grid_step and the six planes enclose the record's box with
+ * at least half a step to spare --, and a word: byte offset (16 per record) of the first record after the subtree for
+ * an interior record, (slot << 4) | 1 for a leaf.  leaf_records: 16 floats per triangle slot = p0, e1, e2 (nine
+ * floats), pMin.x, pMin.y, reference position of the leaf (uint32 bits), pMin.z, pMax.xyz: the leaf's own box as in
+ * fast_nodes, bit for bit.  n_grid_nodes is 0 for any other scene. */
 typedef struct rt_layout_view {
     uint32_t n_fast_nodes, n_ref_nodes, n_tri_slots, n_sphere_slots;
     const float *fast_nodes;
     const float *ref_nodes;
     const float *tri_pos;
     const float *spheres;
+    uint32_t n_grid_nodes;
+    const uint32_t *grid_nodes;
+    const float *leaf_records;
+    float grid_origin[3], grid_step[3];
     void *owner_;
 } rt_layout_view;
 int rt_layout_scene(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt_tri *tris, uint32_t n_tris,

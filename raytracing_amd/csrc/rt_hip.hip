@@ -1653,6 +1653,13 @@ int rt_layout_scene(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const
     out->ref_nodes = reinterpret_cast<const float *>(L->dn.data());
     out->tri_pos = reinterpret_cast<const float *>(L->tp.data());
     out->spheres = reinterpret_cast<const float *>(L->sp.data());
+    if (L->compact) {
+        out->n_grid_nodes = L->n_fast;
+        out->grid_nodes = reinterpret_cast<const uint32_t *>(L->cn.data());
+        out->leaf_records = reinterpret_cast<const float *>(L->lb.data());
+        std::memcpy(out->grid_origin, L->q_origin, sizeof(out->grid_origin));
+        std::memcpy(out->grid_step, L->q_step, sizeof(out->grid_step));
+    }
     out->owner_ = L;
     return RT_OK;
 }

@@ -169,7 +169,9 @@ class OldScene:
 
 def device_layout(scene):
     """What rt_upload_scene lays out for the device, as numpy arrays (host-only; rt_layout_scene): a dict with
-    `fast` and `ref` node records (n, 8) float32, `tri_pos` (slots, 12) and `spheres` (slots, 8)."""
+    `fast` and `ref` node records (n, 8) float32, `tri_pos` (slots, 12) and `spheres` (slots, 8); for flat scenes also
+    `grid` (n, 4) uint32, `leaf_records` (slots, 16) float32, `grid_origin` and `grid_step` (3,) float32 (`grid` is
+    empty for other scenes)."""
     nodes, tris, sph, mats = scene.nodes(), scene.tris(), scene.spheres(), scene.materials()
 
     def ptr(a):
@@ -185,6 +187,10 @@ def device_layout(scene):
             return np.zeros((0, cols), dtype=np.float32)
         return np.ctypeslib.as_array(p, shape=(rows, cols)).copy()
     out = {"fast": grab(v.fast_nodes, v.n_fast_nodes, 8), "ref": grab(v.ref_nodes, v.n_ref_nodes + 1, 8),
-           "tri_pos": grab(v.tri_pos, v.n_tri_slots, 12), "spheres": grab(v.spheres, v.n_sphere_slots, 8)}
+           "tri_pos": grab(v.tri_pos, v.n_tri_slots, 12), "spheres": grab(v.spheres, v.n_sphere_slots, 8),
+           "grid": (np.ctypeslib.as_array(v.grid_nodes, shape=(v.n_grid_nodes, 4)).copy() if v.n_grid_nodes
+                    else np.zeros((0, 4), dtype=np.uint32)),
+           "leaf_records": grab(v.leaf_records, v.n_tri_slots if v.n_grid_nodes else 0, 16),
+           "grid_origin": np.array(list(v.grid_origin), dtype=np.float32), "grid_step": np.array(list(v.grid_step), dtype=np.float32)}
     N.hip().rt_layout_free(C.byref(v))
     return out

@@ -120,6 +120,58 @@ def check_scene(scene):
     return lay, seen
 
 
+def check_grid(lay, flat):
+    """The grid records of a flat scene against its fast tree: same order and links, leaves with their slots, every box
+    enclosed by its six planes with at least half a grid step to spare and by no more than three (the planes are the next
+    grid lines but one), leaf records = triangle + the leaf's own box bit for bit."""
+    fast, grid = lay["fast"], lay["grid"]
+    if not flat:
+        assert len(grid) == 0 and len(lay["leaf_records"]) == 0
+        return
+    assert len(grid) == len(fast) and len(lay["leaf_records"]) == len(lay["tri_pos"])
+    origin, step = lay["grid_origin"].astype(np.float64), lay["grid_step"].astype(np.float64)
+    assert np.all(step > 0)
+    q_lo = np.stack([grid[:, k] & 0xFFFF for k in range(3)], 1).astype(np.float64)
+    q_hi = np.stack([grid[:, k] >> 16 for k in range(3)], 1).astype(np.float64)
+    lo, hi = origin + q_lo * step, origin + q_hi * step
+    bmin, bmax = fast[:, 0:3].astype(np.float64), fast[:, 3:6].astype(np.float64)
+    assert np.all(lo <= bmin - 0.5 * step) and np.all(hi >= bmax + 0.5 * step)
+    assert np.all(lo >= bmin - 3.0 * step) and np.all(hi <= bmax + 3.0 * step)
+    skip, word = u32(fast[:, 6]), u32(fast[:, 7])
+    leaf = (word & 7) == KIND_TRI
+    assert np.array_equal(grid[leaf, 3], ((word[leaf] >> 3) << 4) | 1)
+    assert np.array_equal(grid[~leaf, 3], (skip[~leaf] // 32) * 16)
+    rec, tp = lay["leaf_records"], lay["tri_pos"]
+    slots = word[leaf] >> 3
+    assert np.array_equal(u32(rec[slots, 0:9]), u32(tp[slots, 0:9])) and np.array_equal(u32(rec[slots, 11]), u32(tp[slots, 11]))
+    box = np.concatenate([rec[slots, 9:11], rec[slots, 12:16]], 1)
+    assert np.array_equal(u32(box), u32(fast[leaf, 0:6]))
+    # the grid covers the scene: plane 0 and plane 65535 lie outside the root box on every axis
+    assert np.all(origin < bmin[0]) and np.all(origin + 65535.0 * step > bmax[0])
+
+
+def test_grid_records_of_flat_scenes():
+    for scene in (R.SdScene().load_obj(WL.DRAGON_2426).finalize(), R.SdScene().load_obj(WL.DRAGON_18520).finalize()):
+        check_grid(R.device_layout(scene), True)
+    tris, _ = objparse.load_obj(WL.CYLINDER)
+    # a mesh on a ground quad a hundred times its size; a scene of no thickness; a scene far from the origin
+    check_grid(R.device_layout(R.SdScene().add_model(tris).add_model(WL.ground_quad(y=-1.0, x0=-200.0, x1=200.0, z0=-200.0, z1=200.0)).finalize()), True)
+    flat = R.device_layout(R.SdScene().add_model(WL.ground_quad()).finalize())
+    check_grid(flat, True)
+    assert flat["grid_step"][1] * 65530.0 >= (flat["fast"][0, 3:6] - flat["fast"][0, 0:3]).max() / 8.0 * 0.999  # thin axis: an eighth of the largest extent
+    far = tris.copy().reshape(-1, 3, 8)
+    far[:, :, 0:3] += np.float32(300.0)
+    check_grid(R.device_layout(R.SdScene().add_model(far.reshape(-1, 24)).finalize()), True)
+
+
+def test_pointer_scenes_have_no_grid_records():
+    check_grid(R.device_layout(WL.build_old_scene(WL.rtiow_spheres()).build()), False)
+    tris, _ = objparse.load_obj(WL.CYLINDER)
+    sc = WL.build_old_scene(WL.small_sphere_scene())
+    sc.add_mesh(tris, R.MAT_LAMBERTIAN, (0.8, 0.3, 0.3, 1.0), 0.0)
+    check_grid(R.device_layout(sc.build()), False)
+
+
 def test_flat_scene_layout_dragon2426():
     lay, seen = check_scene(R.SdScene().load_obj(WL.DRAGON_2426).finalize())
     assert len(seen) == 2426 and len(lay["fast"]) == 2 * 2426 - 1
