@@ -164,6 +164,86 @@ def test_grid_records_of_flat_scenes():
     check_grid(R.device_layout(R.SdScene().add_model(far.reshape(-1, 24)).finalize()), True)
 
 
+def _slab_pass(lo, hi, o, inv):
+    """The walk's slab test with closest = +inf in fp32 (fmaxf / fminf drop a NaN operand), boxes (n, 3), one ray."""
+    f = np.float32
+    with np.errstate(invalid="ignore", over="ignore"):
+        t0, t1 = ((lo - o).astype(f) * inv).astype(f), ((hi - o).astype(f) * inv).astype(f)
+    neg = inv < 0
+    near, far = np.where(neg, t1, t0), np.where(neg, t0, t1)
+    tmin = np.fmax(near[:, 2], np.fmax(near[:, 1], np.fmax(near[:, 0], f(1e-6))))
+    tmax = np.fmin(far[:, 2], np.fmin(far[:, 1], np.fmin(far[:, 0], f(np.inf))))
+    return ~(tmax <= tmin)
+
+
+def _grid_pass(q_lo, q_hi, origin, step, o, inv):
+    """The grid walk's test as the kernel evaluates it (grid_axis / grid_box_missed in rt_walks.hpp): per axis
+    t = fma(q, A, B) with A = step * inv, B = (origin - o) * inv, or, for |inv| > 1e25, A = +-1e30, B = -((o - origin) / step) * A."""
+    f = np.float32
+    A, B = np.zeros(3, f), np.zeros(3, f)
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        for k in range(3):
+            if abs(inv[k]) > 1e25:
+                A[k] = f(np.copysign(f(1e30), inv[k]))
+                B[k] = f(-f(f(o[k] - origin[k]) / step[k]) * A[k])
+            else:
+                A[k] = f(step[k] * inv[k])
+                B[k] = f(f(origin[k] - o[k]) * inv[k])
+        fma = lambda q: (q.astype(np.float64) * A.astype(np.float64) + B.astype(np.float64)).astype(f)  # products of floats are exact in double
+        t0, t1 = fma(q_lo), fma(q_hi)
+    neg = inv < 0
+    near, far = np.where(neg, t1, t0), np.where(neg, t0, t1)
+    tmin = np.fmax(near[:, 2], np.fmax(near[:, 1], np.fmax(near[:, 0], f(1e-6))))
+    tmax = np.fmin(far[:, 2], np.fmin(far[:, 1], np.fmin(far[:, 0], f(np.inf))))
+    return ~(tmax <= tmin)
+
+
+def test_grid_walk_never_prunes_what_the_exact_walk_keeps():
+    """Conservativeness of the grid records under the kernel's own fp32 arithmetic: whenever a ray meets a record's exact box
+    it meets the record's grid box -- for rays from inside the scene, from a camera up to 32 grid extents away, along the
+    coordinate axes (infinite 1 / d) and nearly along them."""
+    rng = np.random.default_rng(5)
+    tris, _ = objparse.load_obj(WL.CYLINDER)
+    scenes = [R.SdScene().load_obj(WL.DRAGON_2426).finalize(),
+              R.SdScene().add_model(tris).add_model(WL.ground_quad(y=-1.0, x0=-200.0, x1=200.0, z0=-200.0, z1=200.0)).finalize()]
+    f = np.float32
+    for scene in scenes:
+        lay = R.device_layout(scene)
+        fast, grid = lay["fast"], lay["grid"]
+        origin, step = lay["grid_origin"], lay["grid_step"]
+        q_lo = np.stack([grid[:, k] & 0xFFFF for k in range(3)], 1).astype(f)
+        q_hi = np.stack([grid[:, k] >> 16 for k in range(3)], 1).astype(f)
+        lo, hi = fast[:, 0:3], fast[:, 3:6]
+        root_lo, root_hi = lo[0].astype(np.float64), hi[0].astype(np.float64)
+        ext = (step.astype(np.float64) * 65536.0)
+        kept = pruned_by_grid = 0
+        for i in range(300):
+            if i % 3 == 0:      # from a surface point towards anywhere
+                j = rng.integers(len(fast))
+                o = (lo[j] + (hi[j] - lo[j]) * rng.random(3)).astype(f)
+            elif i % 3 == 1:    # from a camera far outside, towards the scene
+                o = (root_lo + ext * rng.uniform(-30.0, 31.0, 3)).astype(f)
+            else:               # from just outside the root box
+                o = (root_lo + (root_hi - root_lo) * rng.uniform(-0.2, 1.2, 3)).astype(f)
+            target = root_lo + (root_hi - root_lo) * rng.random(3)
+            d = (target - o.astype(np.float64)) if i % 3 else rng.normal(size=3)
+            d = (d / np.linalg.norm(d)).astype(f)
+            if i % 10 == 7:
+                d[rng.integers(3)] = f(0.0)                      # along a coordinate plane
+            if i % 10 == 8:
+                d = np.zeros(3, f); d[rng.integers(3)] = f(rng.choice([-1.0, 1.0]))  # along an axis
+            if i % 10 == 9:
+                d[rng.integers(3)] = f(rng.choice([-1.0, 1.0]) * 1e-30)   # 1 / d overflows the products
+            with np.errstate(divide="ignore"):
+                inv = (f(1.0) / d).astype(f)
+            exact = _slab_pass(lo, hi, o, inv)
+            gridp = _grid_pass(q_lo, q_hi, origin, step, o, inv)
+            assert not np.any(exact & ~gridp), (i, o, d)
+            kept += int(exact.sum())
+            pruned_by_grid += int((~gridp).sum())
+        assert kept > 1000 and pruned_by_grid > 100 * 300    # the rays do meet the scene, and the grid does prune
+
+
 def test_pointer_scenes_have_no_grid_records():
     check_grid(R.device_layout(WL.build_old_scene(WL.rtiow_spheres()).build()), False)
     tris, _ = objparse.load_obj(WL.CYLINDER)
