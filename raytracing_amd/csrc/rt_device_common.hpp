@@ -35,6 +35,8 @@ constexpr int kSliceExtraRounds = 0;       // k_sliced: launches beyond one per 
 constexpr uint32_t kSliceTailRays = 12u << 20;    // k_sliced: a round with no more rays than this is finished by the re-fill kernel (1 ... 32 Mi swept)
 constexpr uint32_t kSliceTailRaysBig = 24u << 20; // ... in scenes beyond the L2s
 constexpr int kChunkSamples = 64;          // samples per pixel traced per wavefront chunk
+constexpr int kMaxChunkSamples = 512;      // ... of a share of a frame, or of a small frame
+constexpr size_t kChunkItems = 144u << 20; // pixel samples a chunk is filled up to (64 samples of a 1080p frame: 133 M)
 constexpr size_t kMaxItems = 192u << 20;   // work items (pixel samples) per chunk: bounds the queue workspace
 
 // ------------------------------------------------------------------ kernel parameters

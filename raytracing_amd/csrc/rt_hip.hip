@@ -305,7 +305,7 @@ int sync_all(rt_ctx *ctx) {
 // (RT_DEBUG_LAYOUT=1 prints what an upload measured about the scene's fast tree to stderr.)
 struct Tuning {
     uint32_t slice = 0, tail_rays = kTailRays, slice_tail_rays = 0; // slice, slice_tail_rays 0: chosen per scene
-    int extra_rounds = kSliceExtraRounds, chunk_samples = kChunkSamples;
+    int extra_rounds = kSliceExtraRounds, chunk_samples = 0; // chunk_samples 0: by the size of the share (chunk_samples())
     int compact = 1; // RT_COMPACT=0: no walk takes the compact tree; 2: traces that collect statistics take it too
     int refill_tail = 1; // RT_REFILL_TAIL=0: k_sliced finishes its last round itself
     int slice_quorum = kSliceQuorum; // RT_SLICE_QUORUM
@@ -324,7 +324,7 @@ const Tuning &tuning() {
         v.tail_rays = (uint32_t)env("RT_TAIL_RAYS", 0, 1 << 30, kTailRays);
         v.slice_tail_rays = (uint32_t)env("RT_TAIL_RAYS", 0, 1 << 30, 0);
         v.extra_rounds = (int)env("RT_EXTRA_ROUNDS", -32, 32, kSliceExtraRounds);
-        v.chunk_samples = (int)env("RT_CHUNK_SAMPLES", 1, kChunkSamples, kChunkSamples);
+        v.chunk_samples = (int)env("RT_CHUNK_SAMPLES", 1, kMaxChunkSamples, 0);
         v.compact = (int)env("RT_COMPACT", 0, 2, 1);
         v.refill_tail = (int)env("RT_REFILL_TAIL", 0, 1, 1);
         v.slice_quorum = (int)env("RT_SLICE_QUORUM", 0, 64, kSliceQuorum);
@@ -518,8 +518,21 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
 
 // Samples per chunk: as many as `max_items` pixel samples allow (the tail of deep bounces is paid once per chunk), and
 // few enough that the colour slot s * npix + pixel of every sample stays a 32-bit number.
+// A chunk holds up to 64 samples of a whole 1080p frame; a share of a frame (tile split over several GPUs) or a small
+// frame gets as many samples more as keep the chunk that size, up to 512, so that its launches stay as large -- and as
+// efficient -- as the whole frame's (measured: an eighth of the 1080p frame in chunks of 64 samples takes 10.0 ms per
+// 512 spp against 44.3 for the whole frame, 5.6 ms in one chunk of 512).
 int chunk_samples(const Plan &pl, size_t max_items) {
-    int S = pl.count < tuning().chunk_samples ? pl.count : tuning().chunk_samples;
+    int cap = tuning().chunk_samples;
+    if (cap == 0) {
+        cap = kChunkSamples;
+        if (pl.items_per_sample > 0) {
+            const size_t fit = kChunkItems / pl.items_per_sample / 64 * 64;
+            if (fit > (size_t)cap)
+                cap = fit > (size_t)kMaxChunkSamples ? kMaxChunkSamples : (int)fit;
+        }
+    }
+    int S = pl.count < cap ? pl.count : cap;
     if (pl.items_per_sample > 0 && (size_t)S * pl.items_per_sample > max_items)
         S = (int)(max_items / pl.items_per_sample);
     if ((size_t)S * pl.npix > 0xFFFFFFFFull)
@@ -669,10 +682,13 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
 }
 
 int launch_fold(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t stream, const KParams &P) {
+    const unsigned blocks = (P.n_my_tiles + 3u) / 4u; // four tiles per block, one per wave
+    if (blocks == 0)
+        return RT_OK;
     if (pl.variant & 2)
-        hipLaunchKernelGGL((k_fold<true>), dim3((unsigned)((pl.npix + 255) / 256)), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((k_fold<true>), dim3(blocks), dim3(256), 0, stream, P);
     else
-        hipLaunchKernelGGL((k_fold<false>), dim3((unsigned)((pl.npix + 255) / 256)), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((k_fold<false>), dim3(blocks), dim3(256), 0, stream, P);
     RT_HIP_CHECK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -748,7 +764,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         rt_ctx::Pipe &pp = ctx->pipes[ctx->next_pipe];
         ctx->next_pipe ^= 1;
         {
-            const int wrc = ensure_workspace(ctx, pp, need_colors, need_q4, pl.npix);
+            const int wrc = ensure_workspace(ctx, pp, need_colors, need_q4, pl.npix * (size_t)((S + 63) / 64));
             if (wrc != RT_OK)
                 return wrc;
         }
@@ -1370,7 +1386,7 @@ int rt_reserve(rt_ctx *ctx, int width, int height, int n_samples) {
         const size_t need_colors = (size_t)S * pl.npix, need_q4 = queue_records((size_t)S * pl.items_per_sample) * 6;
         const int chunks = (n_samples + S - 1) / S;
         for (int p = 0; p < (chunks > 1 || c->pipelining ? 2 : 1); p++) {
-            const int rc = ensure_workspace(c, c->pipes[p], need_colors, need_q4, pl.npix);
+            const int rc = ensure_workspace(c, c->pipes[p], need_colors, need_q4, pl.npix * (size_t)((S + 63) / 64));
             if (rc != RT_OK)
                 return rc;
         }

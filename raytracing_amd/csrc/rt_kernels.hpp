@@ -997,53 +997,57 @@ __global__ void __launch_bounds__(256) k_camera(const KParams P) {
         const int y = (int)tile_y * 8 + (int)(lane >> 3);
         const bool live = x < P.W && y < P.H;
         const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
-        unsigned long long mask = 0ull;
-        if (live) {
-            for (int s = 0; s < P.S; s++) {
-                uint32_t key;
-                f3 d;
-                camera_ray(P, x, y, pixel, P.chunk_first + s, key, d);
-                const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
-                if (meets_root_box(root_a, root_b, P.cam_pos, inv))
-                    mask |= 1ull << s;
+        // (64 samples at a time: one word of the pixel's `deferred` mask, one reservation in the queue)
+        for (int s0 = 0; s0 < P.S; s0 += 64) {
+            const int sb = P.S - s0 < 64 ? P.S - s0 : 64;
+            unsigned long long mask = 0ull;
+            if (live) {
+                for (int s = 0; s < sb; s++) {
+                    uint32_t key;
+                    f3 d;
+                    camera_ray(P, x, y, pixel, P.chunk_first + s0 + s, key, d);
+                    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
+                    if (meets_root_box(root_a, root_b, P.cam_pos, inv))
+                        mask |= 1ull << s;
+                }
+                P.deferred[(size_t)(s0 >> 6) * P.npix + pixel] = mask;
+                n_sky += (unsigned long long)(sb - __builtin_popcountll(mask));
+                if (P.primary != nullptr && s0 == 0 && P.chunk_first == P.first_sample && !(mask & 1ull))
+                    P.primary[pixel] = kNone;
             }
-            P.deferred[pixel] = mask;
-            n_sky += (unsigned long long)(P.S - __builtin_popcountll(mask));
-            if (P.primary != nullptr && P.chunk_first == P.first_sample && !(mask & 1ull))
-                P.primary[pixel] = kNone;
-        }
-        // ---- the samples that get past the root box: one reservation for the tile, records sample-major ----
-        uint32_t mine = (uint32_t)__builtin_popcountll(mask), total = mine;
-        for (int off = 32; off > 0; off >>= 1)
-            total += (uint32_t)__shfl_xor((int)total, off, 64);
-        if (total == 0u)
-            continue;
-        const uint32_t q = j & (uint32_t)(kSubQueues - 1);
-        unsigned int base = 0;
-        if (lane == 0)
-            base = atomicAdd(P.sub_out + q * 32u, total);
-        base = __builtin_amdgcn_readfirstlane(base);
-        unsigned int lo32 = (unsigned int)mask, hi32 = (unsigned int)(mask >> 32);
-        for (int off = 32; off > 0; off >>= 1) { // wave-wide OR of the masks: the samples somebody queued
-            lo32 |= (unsigned int)__shfl_xor((int)lo32, off, 64);
-            hi32 |= (unsigned int)__shfl_xor((int)hi32, off, 64);
-        }
-        unsigned long long any = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)hi32) << 32) |
-                                 (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)lo32);
-        while (any != 0ull) {
-            const int s = __builtin_ctzll(any);
-            any &= any - 1ull;
-            const bool has = (mask >> s) & 1ull;
-            const unsigned long long bm = __ballot(has);
-            if (has) {
-                uint32_t key;
-                f3 d;
-                camera_ray(P, x, y, pixel, P.chunk_first + s, key, d);
-                const size_t slot = (size_t)base + (size_t)__builtin_popcountll(bm & below);
-                const uint32_t cidx = (uint32_t)s * P.npix + pixel;
-                P.q_out[REC4 * ((size_t)q * P.sub_cap) + slot] = make_float4(d.x, d.y, d.z, __uint_as_float(cidx));
+            // ---- the samples that get past the root box: one reservation for the tile, records sample-major ----
+            uint32_t mine = (uint32_t)__builtin_popcountll(mask), total = mine;
+            for (int off = 32; off > 0; off >>= 1)
+                total += (uint32_t)__shfl_xor((int)total, off, 64);
+            if (total == 0u)
+                continue;
+            const uint32_t q = j & (uint32_t)(kSubQueues - 1);
+            unsigned int base = 0;
+            if (lane == 0)
+                base = atomicAdd(P.sub_out + q * 32u, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            unsigned int lo32 = (unsigned int)mask, hi32 = (unsigned int)(mask >> 32);
+            for (int off = 32; off > 0; off >>= 1) { // wave-wide OR of the masks: the samples somebody queued
+                lo32 |= (unsigned int)__shfl_xor((int)lo32, off, 64);
+                hi32 |= (unsigned int)__shfl_xor((int)hi32, off, 64);
             }
-            base += (unsigned int)__builtin_popcountll(bm);
+            unsigned long long any = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)hi32) << 32) |
+                                     (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)lo32);
+            while (any != 0ull) {
+                const int s = __builtin_ctzll(any);
+                any &= any - 1ull;
+                const bool has = (mask >> s) & 1ull;
+                const unsigned long long bm = __ballot(has);
+                if (has) {
+                    uint32_t key;
+                    f3 d;
+                    camera_ray(P, x, y, pixel, P.chunk_first + s0 + s, key, d);
+                    const size_t slot = (size_t)base + (size_t)__builtin_popcountll(bm & below);
+                    const uint32_t cidx = (uint32_t)(s0 + s) * P.npix + pixel;
+                    P.q_out[REC4 * ((size_t)q * P.sub_cap) + slot] = make_float4(d.x, d.y, d.z, __uint_as_float(cidx));
+                }
+                base += (unsigned int)__builtin_popcountll(bm);
+            }
         }
     }
     // a sample that ends here is one closest-hit search of one slab test
@@ -1060,23 +1064,26 @@ __global__ void __launch_bounds__(256) k_camera(const KParams P) {
 // buffer, or -- camera stage, sample not deferred -- is the sky seen by its camera ray, worked out here.
 template <bool OLD>
 __global__ void __launch_bounds__(256) k_fold(const KParams P) {
-    const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
-    if (pixel >= P.npix)
+    // one wave per owned 8x8 tile (every lane has a pixel, whatever share of the frame this device renders)
+    const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (j >= P.n_my_tiles)
         return;
-    const uint32_t x = pixel % (uint32_t)P.W, y = pixel / (uint32_t)P.W;
-    if (P.tile_world > 1) {
-        const uint32_t tile = (y >> 3) * (uint32_t)P.tiles_x + (x >> 3);
-        if ((int)(tile % (uint32_t)P.tile_world) != P.tile_rank)
-            return;
-    }
+    const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
+    const uint32_t tile_y = fastdiv(tile, P.div_tiles_x);
+    const uint32_t x = (tile - tile_y * (uint32_t)P.tiles_x) * 8u + (lane & 7u), y = tile_y * 8u + (lane >> 3);
+    if (x >= (uint32_t)P.W || y >= (uint32_t)P.H)
+        return;
+    const uint32_t pixel = y * (uint32_t)P.W + x;
     float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
     if (P.chunk_first > 1)
         px = P.image_in[pixel];
-    const unsigned long long mask = P.camera_stage ? P.deferred[pixel] : ~0ull;
+    unsigned long long mask = ~0ull;
     for (int s = 0; s < P.S; s++) {
         const int n = P.chunk_first + s;
+        if (P.camera_stage && (s & 63) == 0)
+            mask = P.deferred[(size_t)(s >> 6) * P.npix + pixel]; // one word per 64 samples of the chunk
         float4 c;
-        if ((mask >> s) & 1ull) {
+        if ((mask >> (s & 63)) & 1ull) {
             c = P.colors[(size_t)s * P.npix + pixel];
         } else {
             uint32_t key;
