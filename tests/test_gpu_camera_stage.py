@@ -100,3 +100,31 @@ def test_pointer_scene(tracer, trav):
         assert np.array_equal(prim, oprim), stage
         assert np.array_equal(bits(img), bits(oimg)), stage
         assert (st.rays, st.sph_tests > 0) == (ost.rays, True)
+
+
+def test_chunk_of_more_than_64_samples(tracer, dragon):
+    """A small frame (or a share of a frame) is traced in chunks of up to 512 samples: the camera stage then keeps several
+    64-bit words of its sky mask per pixel.  200 samples in one call against the oracle, and against calls of 64."""
+    ps, os_ = dragon
+    tracer.upload(ps)
+    tracer.set_camera(FAR_CAMERA)
+    oimg, oprim, ost = os_.render(oracle_camera(FAR_CAMERA), O.make_options(bounce_limit=4, seed=21, trig=O.TRIG_POLY), 96, 54, 1, 200,
+                                  want_primary=True)
+    for stage in (R.CAMERA_SEPARATE, R.CAMERA_FUSED):
+        tracer.set_options(bounce_limit=4, seed=21, camera_stage=stage)
+        img, prim, st = tracer.trace(96, 54, 1, 200, want_primary=True)
+        assert np.array_equal(prim, oprim) and np.array_equal(bits(img), bits(oimg)) and st.rays == ost.rays, stage
+        for first in (1, 65, 129, 193):
+            part, _, _ = tracer.trace(96, 54, first, min(64, 201 - first))
+        assert np.array_equal(bits(part), bits(oimg)), stage
+    # a third of the tiles of a larger frame, 300 samples: the share's chunk holds them all
+    tracer.set_options(bounce_limit=3, seed=4)
+    whole, _, wst = tracer.trace(331, 187, 1, 300)
+    acc, rays = np.zeros_like(whole), 0
+    for r in range(3):
+        tracer.set_options(bounce_limit=3, seed=4, tile_rank=r, tile_world=3, camera_stage=R.CAMERA_SEPARATE)
+        part, _, s = tracer.trace(331, 187, 1, 300)
+        assert np.all((acc == 0) | (part == 0))
+        acc += part
+        rays += s.rays
+    assert rays == wst.rays and np.array_equal(bits(whole), bits(acc))
