@@ -14,7 +14,7 @@ for r in csv.DictReader(sys.stdin):
     for k, name in (('SQ_INSTS_VMEM_RD', 'vmem'), ('SQ_INSTS_SALU', 'salu'), ('SQ_INSTS_LDS', 'lds'), ('SQ_LDS_BANK_CONFLICT', 'lds_conflict_cyc')):
         if f(k) is not None: out.append('%s=%.3g' % (name, f(k)))
     if f('TA_TA_BUSY_sum') is not None: out.append('TA=%.2f' % (f('TA_TA_BUSY_sum') / 256 / g))
-    out.append('valu_util=%.2f' % (iv * 4 / 1024 / g))
+    out.append('valu_util=%.2f' % (iv * 2 / 1024 / g))  # a wave64 VALU instruction holds its SIMD-32 for 2 cycles
     if f('SQ_WAVES') is not None: out.append('waves=%.0f' % f('SQ_WAVES'))
     if f('SQ_WAVE_CYCLES') is not None: out.append('occ=%.1f' % (f('SQ_WAVE_CYCLES') / 4 / 1024 / g))
     if f('SQ_WAIT_INST_ANY') is not None and f('SQ_WAVE_CYCLES'): out.append('wait=%.2f' % (f('SQ_WAIT_INST_ANY') / f('SQ_WAVE_CYCLES')))

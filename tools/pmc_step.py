@@ -27,8 +27,9 @@ out = {
     "hbm_bytes_per_step": int((2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0),
     "hbm_read_bytes_per_step": int(2.0 * tot["FETCH_SIZE"] * 1024.0),
     "hbm_write_bytes_per_step": int(tot["WRITE_SIZE"] * 1024.0),
-    # a VALU instruction occupies its SIMD's issue for 4 cycles; kernels of one call run one after the other
-    "valu_issue_utilisation": tot["SQ_INSTS_VALU"] * 4.0 / (simds * cycles),
+    # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (one wave alone issues one per 4 cycles, so it takes
+    # two or more waves to reach this rate); kernels of one call run one after the other
+    "valu_issue_utilisation": tot["SQ_INSTS_VALU"] * 2.0 / (simds * cycles),
     "active_lanes": tot["SQ_THREAD_CYCLES_VALU"] / tot["SQ_INSTS_VALU"],
     "valu_instructions_per_step": tot["SQ_INSTS_VALU"],
     "vmem_read_instructions_per_step": tot.get("SQ_INSTS_VMEM_RD"),
