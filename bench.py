@@ -267,7 +267,8 @@ def main():
         on_die = scene_bytes <= MALL_BYTES
         if on_die:
             # node and triangle records are served by the L2s (<= 32 MB) or the Infinity Cache (<= 256 MB): HBM carries the
-            # queues and the image only, and what bounds the walk is VALU issue under divergence (and the latency behind it)
+            # queues and the image only; the roof the walk is priced against is VALU arithmetic (what binds it in practice is the
+            # vector-memory path: valu_issue_utilisation and the texture-addresser figure of the counter passes say how far)
             roof = {"bound": "valu", "achieved": alg_ops / secs / 1e12, "peak": VALU_PEAK_TOPS, "unit": "Tops/s",
                     "frac": alg_ops / secs / 1e12 / VALU_PEAK_TOPS, "traffic": traffic,
                     "algorithmic_ops_per_launch": int(alg_ops),
