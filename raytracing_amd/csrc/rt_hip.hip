@@ -309,6 +309,7 @@ struct Tuning {
     int compact = 1; // RT_COMPACT=0: no walk takes the compact tree; 2: traces that collect statistics take it too
     int refill_tail = 1; // RT_REFILL_TAIL=0: k_sliced finishes its last round itself
     int slice_quorum = kSliceQuorum; // RT_SLICE_QUORUM
+    int lds_pad = 0; // RT_LDS_PAD: bytes of unused LDS added to every path-kernel block (fewer blocks per CU: occupancy experiments)
 };
 const Tuning &tuning() {
     static const Tuning t = [] {
@@ -328,6 +329,7 @@ const Tuning &tuning() {
         v.compact = (int)env("RT_COMPACT", 0, 2, 1);
         v.refill_tail = (int)env("RT_REFILL_TAIL", 0, 1, 1);
         v.slice_quorum = (int)env("RT_SLICE_QUORUM", 0, 64, kSliceQuorum);
+        v.lds_pad = (int)env("RT_LDS_PAD", 0, 40 << 10, 0);
         return v;
     }();
     return t;
@@ -585,6 +587,7 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
     const bool sliced = pl.sliced, queued = pl.queued, refill = pl.refill;
     const bool refill_tail = tuning().refill_tail != 0; // the sliced walk's last round is finished with lane re-fill
     const int walk = pl.walk;
+    const unsigned lds_pad = (unsigned)tuning().lds_pad;
     dim3 block(256);
     if (pl.camera) { // level 0: camera rays, root slab test; what passes goes to level 1's queue
         P.level = 0;
@@ -632,20 +635,20 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
         // fetch latency; the spills land in the shading code, which runs once per ray); the others: uncapped
 #define RT_LAUNCH_PATH(OLD_, STATS_)                                                                                  \
     do {                                                                                                              \
-        if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail && !OLD_ && P.compact == 2) hipLaunchKernelGGL((k_refill<false, STATS_, 2, true>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail && !OLD_ && P.compact == 1) hipLaunchKernelGGL((k_refill<false, STATS_, 1, true>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail) hipLaunchKernelGGL((k_refill<OLD_, STATS_, 0, true>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST && sliced && !OLD_ && P.compact == 2) hipLaunchKernelGGL((k_sliced<false, STATS_, 2>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST && sliced && !OLD_ && P.compact == 1) hipLaunchKernelGGL((k_sliced<false, STATS_, 1>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST && sliced) hipLaunchKernelGGL((k_sliced<OLD_, STATS_>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST && queued) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_QUEUED>), grid, block, 0, stream, P); \
-        else if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST && refill && !OLD_ && P.compact == 2) hipLaunchKernelGGL((k_refill<false, STATS_, 2>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST && refill && !OLD_ && P.compact == 1) hipLaunchKernelGGL((k_refill<false, STATS_, 1>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST && refill) hipLaunchKernelGGL((k_refill<OLD_, STATS_>), grid, block, 0, stream, P); \
-        else if (walk == WALK_FAST) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_FAST>), grid, block, 0, stream, P); \
-        else if (walk == WALK_BRUTE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_BRUTE>), grid, block, 0, stream, P); \
-        else hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_LANE>), grid, block, 0, stream, P);                         \
+        if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail && !OLD_ && P.compact == 2) hipLaunchKernelGGL((k_refill<false, STATS_, 2, true>), grid, block, lds_pad, stream, P); \
+        else if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail && !OLD_ && P.compact == 1) hipLaunchKernelGGL((k_refill<false, STATS_, 1, true>), grid, block, lds_pad, stream, P); \
+        else if (walk == WALK_FAST && sliced && P.tail != 0 && refill_tail) hipLaunchKernelGGL((k_refill<OLD_, STATS_, 0, true>), grid, block, lds_pad, stream, P); \
+        else if (walk == WALK_FAST && sliced && !OLD_ && P.compact == 2) hipLaunchKernelGGL((k_sliced<false, STATS_, 2>), grid, block, lds_pad, stream, P); \
+        else if (walk == WALK_FAST && sliced && !OLD_ && P.compact == 1) hipLaunchKernelGGL((k_sliced<false, STATS_, 1>), grid, block, lds_pad, stream, P); \
+        else if (walk == WALK_FAST && sliced) hipLaunchKernelGGL((k_sliced<OLD_, STATS_>), grid, block, lds_pad, stream, P); \
+        else if (walk == WALK_FAST && queued) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_QUEUED>), grid, block, lds_pad, stream, P); \
+        else if (walk == WALK_WAVE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_WAVE>), grid, block, lds_pad, stream, P); \
+        else if (walk == WALK_FAST && refill && !OLD_ && P.compact == 2) hipLaunchKernelGGL((k_refill<false, STATS_, 2>), grid, block, lds_pad, stream, P); \
+        else if (walk == WALK_FAST && refill && !OLD_ && P.compact == 1) hipLaunchKernelGGL((k_refill<false, STATS_, 1>), grid, block, lds_pad, stream, P); \
+        else if (walk == WALK_FAST && refill) hipLaunchKernelGGL((k_refill<OLD_, STATS_>), grid, block, lds_pad, stream, P); \
+        else if (walk == WALK_FAST) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_FAST>), grid, block, lds_pad, stream, P); \
+        else if (walk == WALK_BRUTE) hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_BRUTE>), grid, block, lds_pad, stream, P); \
+        else hipLaunchKernelGGL((k_path<OLD_, STATS_, WALK_LANE>), grid, block, lds_pad, stream, P);                         \
     } while (0)
         // The sliced walk hands a round that no longer fills the chip to the re-fill kernel: launched first, it takes the
         // round only if it is that small (and then k_sliced, launched after it, leaves at once); the last round is always its.
@@ -653,17 +656,17 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
             P.refill_tail = 1;
             switch (pl.variant) {
             case 4:
-                if (P.compact == 2) hipLaunchKernelGGL((k_refill<false, false, 2, true>), grid, block, 0, stream, P);
-                else if (P.compact == 1) hipLaunchKernelGGL((k_refill<false, false, 1, true>), grid, block, 0, stream, P);
-                else hipLaunchKernelGGL((k_refill<false, false, 0, true>), grid, block, 0, stream, P);
+                if (P.compact == 2) hipLaunchKernelGGL((k_refill<false, false, 2, true>), grid, block, lds_pad, stream, P);
+                else if (P.compact == 1) hipLaunchKernelGGL((k_refill<false, false, 1, true>), grid, block, lds_pad, stream, P);
+                else hipLaunchKernelGGL((k_refill<false, false, 0, true>), grid, block, lds_pad, stream, P);
                 break;
             case 5:
-                if (P.compact == 2) hipLaunchKernelGGL((k_refill<false, true, 2, true>), grid, block, 0, stream, P);
-                else if (P.compact == 1) hipLaunchKernelGGL((k_refill<false, true, 1, true>), grid, block, 0, stream, P);
-                else hipLaunchKernelGGL((k_refill<false, true, 0, true>), grid, block, 0, stream, P);
+                if (P.compact == 2) hipLaunchKernelGGL((k_refill<false, true, 2, true>), grid, block, lds_pad, stream, P);
+                else if (P.compact == 1) hipLaunchKernelGGL((k_refill<false, true, 1, true>), grid, block, lds_pad, stream, P);
+                else hipLaunchKernelGGL((k_refill<false, true, 0, true>), grid, block, lds_pad, stream, P);
                 break;
-            case 6: hipLaunchKernelGGL((k_refill<true, false, 0, true>), grid, block, 0, stream, P); break;
-            default: hipLaunchKernelGGL((k_refill<true, true, 0, true>), grid, block, 0, stream, P); break;
+            case 6: hipLaunchKernelGGL((k_refill<true, false, 0, true>), grid, block, lds_pad, stream, P); break;
+            default: hipLaunchKernelGGL((k_refill<true, true, 0, true>), grid, block, lds_pad, stream, P); break;
             }
             RT_HIP_CHECK(ctx, hipGetLastError());
         } else {

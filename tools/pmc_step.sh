@@ -7,6 +7,7 @@ export TMPDIR=/tmp
 mkdir -p $O
 run() { name=$1; shift; timeout -s KILL 300 rocprofv3 --pmc "$@" -d "$O/$name" --output-format csv -- python3 tools/trace_once.py --workload $WL --spp $SPP --reps 1 --camera $CAM > "$O/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$O/$name.log"; exit 1; }; }
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE TA_TA_BUSY_sum
+run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 python tools/pmc_step.py $O "rocprofv3 --pmc passes of tools/trace_once.py --workload $WL --spp $SPP (tools/pmc_step.sh)" > $O/step.json || exit 1
