@@ -209,12 +209,13 @@ def main():
     render(args.warmup)
     tr.sync()
     note("warm-up done")
-    if world > 1:
+    grouped = dist.is_initialized()   # N > 1, or a single rank taken through the collectives (RT_FORCE_DIST=1)
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     render(args.steps)
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -223,7 +224,7 @@ def main():
     assert st.launches == args.steps  # st.rays: closest-hit searches of all the timed steps of this rank
 
     total = torch.tensor([elapsed, float(st.rays)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if grouped:
         tmax = total.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
@@ -375,7 +376,7 @@ def main():
             out["cpu_baseline"] = cb
         print(json.dumps(out))
     tr.close()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -22,11 +22,13 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Returns (rank, world, local_rank); initialises the process group when WORLD_SIZE > 1."""
+    """Returns (rank, world, local_rank); initialises the process group when WORLD_SIZE > 1 -- or when RT_FORCE_DIST=1,
+    which takes a single rank through the very collectives of a multi-rank run (RCCL init, barrier, reduce, all-reduce):
+    the rehearsal a box with one GPU allows."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("RT_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -82,7 +84,7 @@ def _reduce_sum(image, dst):
 def combine_tile_split(image, dst=0):
     """image: this rank's (H, W, 4) float32 tensor, ZERO outside its tiles.  After the call rank `dst` holds the
     assembled image."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         _reduce_sum(image, dst)
     return image
 
@@ -90,7 +92,7 @@ def combine_tile_split(image, dst=0):
 def combine_sample_split(image, dst=0, weight=None):
     """image: this rank's mean over its own samples.  After the call rank `dst` holds the mean over all ranks'
     samples.  weight = this rank's share of the samples (None: equal shares, 1 / world)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         world = dist.get_world_size()
         if weight is not None:
             image *= weight
