@@ -294,6 +294,11 @@ def main():
                      "hbm_frac": traffic / secs / 1e9 / HBM_PEAK_GBS if traffic else None,
                      "valu_issue_utilisation": pmc.get("valu_issue_utilisation"),
                      "active_lanes_per_valu_instruction": pmc.get("active_lanes"),
+                     # what the walk kernels run against in practice: every lane of a wave fetches a record of its own, and a
+                     # compute unit serves such loads at 1.98 cache lines per clock out of its L1 and 0.437 on an L1 miss
+                     # (tools/ta_probe.hip, profiles/r02_ta_probe.txt).  floor = the step's counted line accesses and misses
+                     # (TCP_TOTAL_CACHE_ACCESSES, TCP_TCC_READ_REQ) at those rates; frac = floor / cycles of the step
+                     "vector_memory_path": pmc.get("vector_memory_path"),
                      "counters_from": pmc.get("source")})
         primary = my_pixels * my_spp if wl.bounce_limit > 0 or wl.estimator != R.EST_SD_LOOP else 0
         out = {

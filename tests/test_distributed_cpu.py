@@ -60,3 +60,33 @@ def test_two_rank_partitions_over_gloo(tmp_path):
         assert np.array_equal(bits(np.load(tmp_path / f"tile{attempt}.npy")), bits(full))          # exact, both times
         # sum-then-divide of two running means over disjoint halves of the same sample indices vs one running mean
         assert np.allclose(np.load(tmp_path / f"sample{attempt}.npy"), full, rtol=1e-5, atol=1e-6)
+
+
+def _single_worker(rank, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      RT_FORCE_DIST="1")
+    from raytracing_amd import parallel as P
+    r, w, _ = P.init_from_env("gloo")
+    assert (r, w) == (0, 1) and dist.is_initialized()   # a group of one: the collectives run, and change nothing
+    sc = oracle_sd_scene([WL.CYLINDER])
+    cam = oracle_camera(WL.DEFAULT_CAMERA)
+    for split in ("tile", "sample"):
+        assert P.share_options(split, 0, 1) == {}
+        opt = O.make_options(bounce_limit=4, seed=9, threads=2)
+        t = torch.zeros((H, W, 4), dtype=torch.float32)
+        P.render(lambda i: sc.render(cam, opt, W, H, 1 + i * SPP, SPP, image=t.numpy()), lambda: None, t, STEPS, split, 1)
+        np.save(os.path.join(out_dir, f"one_{split}.npy"), t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_taken_through_the_collectives(tmp_path):
+    """RT_FORCE_DIST=1 (the single-GPU rehearsal of the multi-rank bench): the reduce of a group of one leaves the
+    image bit for bit what a render without any process group gives."""
+    mp.spawn(_single_worker, args=(29900 + (os.getpid() % 90), str(tmp_path)), nprocs=1, join=True)
+    sc = oracle_sd_scene([WL.CYLINDER])
+    full, _, _ = sc.render(oracle_camera(WL.DEFAULT_CAMERA), O.make_options(bounce_limit=4, seed=9), W, H, 1, STEPS * SPP)
+    for split in ("tile", "sample"):
+        assert np.array_equal(bits(np.load(tmp_path / f"one_{split}.npy")), bits(full))
