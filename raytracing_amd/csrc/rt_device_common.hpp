@@ -87,6 +87,7 @@ struct KParams {
     uint32_t sub_cap;           // records a sub-queue can hold; sub-queue q starts at record q * sub_cap
     uint32_t n_items;           // level 0: n_my_tiles * 64 * S
     uint32_t npix;
+    uint32_t cpix;              // colour slots per sample of a chunk: 64 per owned tile (slot = tile ordinal * 64 + pixel in the tile)
     int level, S, chunk_first;
     float jitter;
     f3 cam_pos, bx, by, bz;

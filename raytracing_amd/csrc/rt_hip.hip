@@ -511,6 +511,7 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     P.slice_quorum = (uint32_t)tuning().slice_quorum;
     P.compact = !pl.compact ? 0 : ctx->scene_bytes > kRefillSceneBytes ? 2 : 1; // 2: two records per trip to memory
     P.npix = (uint32_t)pl.npix;
+    P.cpix = (uint32_t)pl.items_per_sample;
     pl.W = W;
     pl.H = H;
     pl.first = first;
@@ -519,7 +520,7 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
 }
 
 // Samples per chunk: as many as `max_items` pixel samples allow (the tail of deep bounces is paid once per chunk), and
-// few enough that the colour slot s * npix + pixel of every sample stays a 32-bit number.
+// few enough that the colour slot of every sample (sample in chunk * slots per sample + slot, pixel_of_slot) stays a 32-bit number.
 // A chunk holds up to 64 samples of a whole 1080p frame; a share of a frame (tile split over several GPUs) or a small
 // frame gets as many samples more as keep the chunk that size, up to 512, so that its launches stay as large -- and as
 // efficient -- as the whole frame's (measured: an eighth of the 1080p frame in chunks of 64 samples takes 10.0 ms per
@@ -537,8 +538,8 @@ int chunk_samples(const Plan &pl, size_t max_items) {
     int S = pl.count < cap ? pl.count : cap;
     if (pl.items_per_sample > 0 && (size_t)S * pl.items_per_sample > max_items)
         S = (int)(max_items / pl.items_per_sample);
-    if ((size_t)S * pl.npix > 0xFFFFFFFFull)
-        S = (int)(0xFFFFFFFFull / pl.npix);
+    if (pl.items_per_sample > 0 && (size_t)S * pl.items_per_sample > 0xFFFFFFFFull)
+        S = (int)(0xFFFFFFFFull / pl.items_per_sample);
     if (S < 1)
         S = 1;
     return S;
@@ -757,7 +758,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     }
     // ---- wavefront: samples in chunks of S; per chunk one launch per bounce level (or round), then k_fold ----
     const int S = chunk_samples(pl, kMaxItems);
-    const size_t need_colors = (size_t)S * pl.npix, need_q4 = queue_records((size_t)S * pl.items_per_sample) * pl.rec4;
+    const size_t need_colors = (size_t)S * pl.items_per_sample, need_q4 = queue_records((size_t)S * pl.items_per_sample) * pl.rec4;
     if (timed)
         RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
@@ -767,7 +768,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
         rt_ctx::Pipe &pp = ctx->pipes[ctx->next_pipe];
         ctx->next_pipe ^= 1;
         {
-            const int wrc = ensure_workspace(ctx, pp, need_colors, need_q4, pl.npix * (size_t)((S + 63) / 64));
+            const int wrc = ensure_workspace(ctx, pp, need_colors, need_q4, pl.items_per_sample * (size_t)((S + 63) / 64));
             if (wrc != RT_OK)
                 return wrc;
         }
@@ -839,7 +840,7 @@ int launch_trace_noalloc(rt_ctx *ctx, int W, int H, int first, int count, float4
     ws.deferred_cap = kScratchMaxItems;
     ws.colors_cap = kScratchMaxItems;
     ws.q_cap = (kScratchMaxItems + kQueueSlack) * 6;
-    const int S = chunk_samples(pl, kScratchMaxItems); // S * npix <= S * items <= kScratchMaxItems: the colours fit too
+    const int S = chunk_samples(pl, kScratchMaxItems); // S * items <= kScratchMaxItems: the colours and the `deferred` words (64 slots per owned tile and sample) fit too
     for (int done = 0; done < count; done += S) {
         const int s_now = count - done < S ? count - done : S;
         KParams P;
@@ -1386,10 +1387,10 @@ int rt_reserve(rt_ctx *ctx, int width, int height, int n_samples) {
         const size_t tiles = (size_t)((width + 7) / 8) * (size_t)((height + 7) / 8);
         pl.items_per_sample = (tiles + (size_t)tile_world - 1) / (size_t)tile_world * 64;
         const int S = chunk_samples(pl, kMaxItems);
-        const size_t need_colors = (size_t)S * pl.npix, need_q4 = queue_records((size_t)S * pl.items_per_sample) * 6;
+        const size_t need_colors = (size_t)S * pl.items_per_sample, need_q4 = queue_records((size_t)S * pl.items_per_sample) * 6;
         const int chunks = (n_samples + S - 1) / S;
         for (int p = 0; p < (chunks > 1 || c->pipelining ? 2 : 1); p++) {
-            const int rc = ensure_workspace(c, c->pipes[p], need_colors, need_q4, pl.npix * (size_t)((S + 63) / 64));
+            const int rc = ensure_workspace(c, c->pipes[p], need_colors, need_q4, pl.items_per_sample * (size_t)((S + 63) / 64));
             if (rc != RT_OK)
                 return rc;
         }

@@ -127,14 +127,24 @@ RT_D bool shade_step(const KParams &P, Path &path, const Best &hit, Cnt &cnt, fl
 
 // shade_step for the wavefront kernels: an ended path's colour goes to colors[sample][pixel], and the primitive met by the
 // camera ray of the call's first sample to the primary-id image.
+// The per-sample buffers of a chunk (colours, `deferred` words) hold 64 slots per OWNED 8x8 tile, in the order this context
+// takes its tiles: slot = tile ordinal * 64 + pixel within the tile.  A share of a frame therefore needs its share of the
+// memory, and a wave's 64 slots are one contiguous kilobyte.  The frame pixel of a slot:
+RT_D uint32_t pixel_of_slot(const KParams &P, const uint32_t slot) {
+    const uint32_t tile = (uint32_t)P.tile_rank + (slot >> 6) * (uint32_t)P.tile_world;
+    const uint32_t tile_y = fastdiv(tile, P.div_tiles_x);
+    const uint32_t x = (tile - tile_y * (uint32_t)P.tiles_x) * 8u + (slot & 7u), y = tile_y * 8u + ((slot >> 3) & 7u);
+    return y * (uint32_t)P.W + x;
+}
+
 template <bool OLD, bool STATS>
 RT_D bool shade_path(const KParams &P, Path &path, const Best &hit, const uint32_t cidx, Cnt &cnt) {
     const bool first = path.depth == 0;
     float4 c;
     uint32_t prim;
     const bool ended = shade_step<OLD, STATS>(P, path, hit, cnt, c, prim);
-    if (first && P.primary != nullptr && P.chunk_first + (int)(cidx / P.npix) == P.first_sample)
-        P.primary[cidx % P.npix] = prim;
+    if (first && P.primary != nullptr && P.chunk_first + (int)(cidx / P.cpix) == P.first_sample)
+        P.primary[pixel_of_slot(P, cidx % P.cpix)] = prim;
     if (ended)
         P.colors[cidx] = c;
     return ended;
@@ -195,7 +205,7 @@ RT_D bool camera_path(const KParams &P, const uint32_t item, Path &path, uint32_
     bool live = item < P.n_items && x < P.W && y < P.H;
     const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
     const int n = P.chunk_first + (int)s;
-    cidx = s * P.npix + pixel;
+    cidx = s * P.cpix + j * 64u + in_tile;
     path.o = P.cam_pos;
     camera_ray(P, x, y, pixel, n, path.key, path.d);
     path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -285,7 +295,7 @@ __global__ void __launch_bounds__(256) k_trace(const KParams P) {
 // rest of the path state of a camera ray is known: origin, unit throughput, depth 0, and the RNG key of (pixel, sample).
 RT_D void read_camera_record(const KParams &P, const float4 r, Path &path, uint32_t &cidx) {
     cidx = __float_as_uint(r.w);
-    const uint32_t s = cidx / P.npix, pixel = cidx - s * P.npix;
+    const uint32_t s = cidx / P.cpix, pixel = pixel_of_slot(P, cidx - s * P.cpix);
     path.o = P.cam_pos;
     path.d = mk3(r.x, r.y, r.z);
     path.thr = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -1010,7 +1020,7 @@ __global__ void __launch_bounds__(256) k_camera(const KParams P) {
                     if (meets_root_box(root_a, root_b, P.cam_pos, inv))
                         mask |= 1ull << s;
                 }
-                P.deferred[(size_t)(s0 >> 6) * P.npix + pixel] = mask;
+                P.deferred[(size_t)(s0 >> 6) * P.cpix + j * 64u + lane] = mask;
                 n_sky += (unsigned long long)(sb - __builtin_popcountll(mask));
                 if (P.primary != nullptr && s0 == 0 && P.chunk_first == P.first_sample && !(mask & 1ull))
                     P.primary[pixel] = kNone;
@@ -1043,7 +1053,7 @@ __global__ void __launch_bounds__(256) k_camera(const KParams P) {
                     f3 d;
                     camera_ray(P, x, y, pixel, P.chunk_first + s0 + s, key, d);
                     const size_t slot = (size_t)base + (size_t)__builtin_popcountll(bm & below);
-                    const uint32_t cidx = (uint32_t)(s0 + s) * P.npix + pixel;
+                    const uint32_t cidx = (uint32_t)(s0 + s) * P.cpix + j * 64u + lane;
                     P.q_out[REC4 * ((size_t)q * P.sub_cap) + slot] = make_float4(d.x, d.y, d.z, __uint_as_float(cidx));
                 }
                 base += (unsigned int)__builtin_popcountll(bm);
@@ -1081,10 +1091,10 @@ __global__ void __launch_bounds__(256) k_fold(const KParams P) {
     for (int s = 0; s < P.S; s++) {
         const int n = P.chunk_first + s;
         if (P.camera_stage && (s & 63) == 0)
-            mask = P.deferred[(size_t)(s >> 6) * P.npix + pixel]; // one word per 64 samples of the chunk
+            mask = P.deferred[(size_t)(s >> 6) * P.cpix + j * 64u + lane]; // one word per 64 samples of the chunk
         float4 c;
         if ((mask >> (s & 63)) & 1ull) {
-            c = P.colors[(size_t)s * P.npix + pixel];
+            c = P.colors[(size_t)s * P.cpix + j * 64u + lane];
         } else {
             uint32_t key;
             f3 d;
