@@ -48,6 +48,7 @@ struct KParams {
     f3 q_origin, q_step;       // ... and the grid its 16-bit planes live on
     int compact;               // the sliced / re-fill walks go over the compact tree (2: two records per trip to memory)
     uint32_t slice_quorum;     // k_sliced: a wave with no more walking lanes than this ends its slice
+    int wave_camera;           // k_sliced: batches of fresh camera rays take the wave-synchronous walk (fast_wave_walk)
     int refill_tail;           // k_sliced leaves a round of at most tail_rays rays to the re-fill kernel launched before it
     const float4 *tri_pos; // 3 x float4 per triangle slot: p0, e1, e2, prim id, material
     const float4 *tri_nrm; // 3 x float4 per triangle slot: n0, n1, n2

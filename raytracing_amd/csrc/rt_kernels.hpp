@@ -870,6 +870,9 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
                 w.mesh = __float_as_uint(r5.w);
             }
         }
+        // A batch of camera rays whose walks have not started holds neighbours -- one tile, one sample (or a few) --: the wave
+        // walks the records they meet together, to the end (fast_wave_walk); everything else goes lane by lane, in slices.
+        bool camera_batch = !OLD && P.wave_camera != 0 && (P.level == 0 || (P.camera_stage != 0 && P.level == 1));
         for (;;) {
             if (__ballot(live) == 0ull)
                 break;
@@ -879,13 +882,20 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
                 if (w.idx == 0u)
                     cnt.rays++; // a walk starts at record 0 and never returns to it
             }
+            if constexpr (!OLD) {
+                if (camera_batch) {
+                    fast_wave_walk<STATS>(P, live, lane, path.o, path.d, path.inv, cnt, J);
+                    if (live)
+                        w.idx = n;
+                }
+            }
             // The slice is walked in bursts; between two bursts the wave runs the tests noted so far if its list is more than
             // half full.  A full list makes the walk test on the spot, a few lanes at a time, which costs far more than a
             // pass of resolve_jobs (the minima per owner stay in the wave's LDS words from one pass to the next).
             GridRay grid;
             if (COMPACT)
                 grid = grid_ray(P, path.o, path.inv);
-            for (int left = slice;;) {
+            for (int left = slice; !camera_batch;) {
                 if (COMPACT && live && w.idx < n) {
                     compact_walk_from<STATS, COMPACT == 2>(P, path.inv, grid, w.idx, left < kSliceBurst ? left : kSliceBurst, cnt,
                                              [&]() { return atomicAdd(&J.count, 1u); },
@@ -929,6 +939,7 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
                 resolve_jobs<OLD>(P, lane, path.o, path.d, J);
             take_noted_result(live, lane, J, best, bpos, bm);
             J.key[lane] = ~0ull;
+            camera_batch = false;
             if (live && !(w.idx < n)) {
                 if (best.ref != kNone && (bm > best.t || P.force_replay != 0)) { // see closest_hit_fast
                     cnt.replay++;

@@ -1004,4 +1004,114 @@ RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint3
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The fast walk for a wave of NEIGHBOURS (the camera rays of one 8x8 tile and one sample): wave-synchronous.
+//
+// Such rays meet nearly the same records -- on the 18 520-triangle dragon at 1080p a lane's own walk is 48 records long,
+// the longest of a tile's 64 is 61, and all 64 together meet 82 different ones -- so the wave walks the UNION: it visits a
+// record when any lane's own walk would, every lane whose walk includes the record tests it, a lane that fails an interior
+// box sits out until the wave reaches that record's skip offset (subtrees are nested intervals of the array, so when every
+// taking-part lane fails, nobody wants anything before the skip offset: the wave's next record is cur + 32 or skip).  The
+// record comes ONCE per wave through the scalar data path (one s_load_dwordx8 into SGPRs) instead of 64 times, one line
+// each, through the vector-memory path the per-lane walk is bound by.  Each lane performs exactly the slab tests of its own
+// fast_walk_from, with the same arithmetic; leaves that pass are noted in the wave's list (places from a ballot: the lanes
+// are in step, no atomic is needed) with the box's entry distance, and run by resolve_jobs, the list being emptied whenever
+// the next leaf might not fit.  Flat scenes (triangles only).  Every lane of the wave must call this.
+template <bool STATS, int OCT> // OCT = sign bits (x | y<<1 | z<<2) shared by the wave's live lanes, or -1 = mixed
+RT_D void fast_wave_walk_oct(const KParams &P, const bool live, const uint32_t lane, const f3 o, const f3 d, const f3 inv, Cnt &cnt,
+                             WaveJobs &J, const bool nx, const bool ny, const bool nz) {
+    constexpr bool UNI = OCT >= 0;
+    constexpr bool ux = UNI && (OCT & 1), uy = UNI && (OCT & 2), uz = UNI && (OCT & 4);
+    typedef const char __attribute__((address_space(4))) *cbytes;
+    const cbytes nodes = (cbytes)(uintptr_t)P.fnodes;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t n = P.n_fnodes * 32u;
+    const float inf = __builtin_inff();
+    uint32_t resume = live ? 0u : kNone; // byte offset of the next record this lane takes part in
+    uint32_t cur = 0u;                    // byte offset of the wave's current record
+    uint32_t count = 0u;                  // jobs in the wave's list (the same in every lane)
+    // (Measured and dropped: asking for the record behind this one as well -- scalar loads return in any order, so a wait for
+    // one is a wait for all: 3.5 % slower -- and records two at a time in one s_load_dwordx16: 15 % slower, the sixteen
+    // registers spill.)
+    while (cur < n) {
+        const v8f r = *(cf8ptr)(nodes + cur);
+        const v4f a = {r[0], r[1], r[2], r[3]}, b = {r[4], r[5], r[6], r[7]};
+        const uint32_t skip = __float_as_uint(b.z), kind = __float_as_uint(b.w);
+        float nearx, farx, neary, fary, nearz, farz;
+        if (UNI) {
+            const float pnx = ux ? a.w : a.x, pfx = ux ? a.x : a.w;
+            const float pny = uy ? b.x : a.y, pfy = uy ? a.y : b.x;
+            const float pnz = uz ? b.y : a.z, pfz = uz ? a.z : b.y;
+            nearx = (pnx - o.x) * inv.x;
+            farx = (pfx - o.x) * inv.x;
+            neary = (pny - o.y) * inv.y;
+            fary = (pfy - o.y) * inv.y;
+            nearz = (pnz - o.z) * inv.z;
+            farz = (pfz - o.z) * inv.z;
+        } else {
+            const float t0x = (a.x - o.x) * inv.x, t1x = (a.w - o.x) * inv.x;
+            const float t0y = (a.y - o.y) * inv.y, t1y = (b.x - o.y) * inv.y;
+            const float t0z = (a.z - o.z) * inv.z, t1z = (b.y - o.z) * inv.z;
+            nearx = nx ? t1x : t0x;
+            farx = nx ? t0x : t1x;
+            neary = ny ? t1y : t0y;
+            fary = ny ? t0y : t1y;
+            nearz = nz ? t1z : t0z;
+            farz = nz ? t0z : t1z;
+        }
+        const float tmin = fmaxf(nearz, fmaxf(neary, fmaxf(nearx, 1e-6f)));
+        const float tmax = fminf(farz, fminf(fary, fminf(farx, inf))); // the slab test with closest = +inf
+        const bool act = resume <= cur;
+        const bool ok = !(tmax <= tmin);
+        if (STATS)
+            cnt.box += act ? 1ull : 0ull;
+        resume = (act && !ok) ? skip : resume; // (a leaf's skip offset is cur + 32)
+        const unsigned long long passed = __builtin_amdgcn_ballot_w64(act && ok);
+        if ((kind & 7u) == KIND_INTERNAL) {
+            if (passed == 0ull) { // nobody goes in: on behind the subtree
+                cur = __builtin_amdgcn_readfirstlane(skip);
+                continue;
+            }
+        } else if (passed != 0ull) {
+            const uint32_t fresh = (uint32_t)__builtin_popcountll(passed);
+            if (count + fresh > kJobCap) { // the list cannot take them: run what it holds (the minima per owner stay in J.key)
+                if (lane == 0)
+                    J.count = count;
+                resolve_jobs<false>(P, lane, o, d, J);
+                count = 0u;
+            }
+            if (act && ok) {
+                if (STATS)
+                    cnt.tri++;
+                const uint32_t slot = kind >> 3;
+                J.jobs[count + (uint32_t)__builtin_popcountll(passed & below)] = make_uint2((lane << kJobSlotBits) | slot, __float_as_uint(tmin));
+            }
+            count += fresh;
+        }
+        cur = __builtin_amdgcn_readfirstlane(cur + 32u);
+    }
+    if (lane == 0)
+        J.count = count;
+    resolve_jobs<false>(P, lane, o, d, J);
+}
 
+template <bool STATS>
+RT_D void fast_wave_walk(const KParams &P, const bool live, const uint32_t lane, const f3 o, const f3 d, const f3 inv, Cnt &cnt, WaveJobs &J) {
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
+    const unsigned long long mx = __builtin_amdgcn_ballot_w64(live && nx), my = __builtin_amdgcn_ballot_w64(live && ny),
+                             mz = __builtin_amdgcn_ballot_w64(live && nz);
+    const bool uniform = (mx == 0ull || mx == lm) && (my == 0ull || my == lm) && (mz == 0ull || mz == lm);
+    const int oct = uniform ? ((mx != 0ull ? 1 : 0) | (my != 0ull ? 2 : 0) | (mz != 0ull ? 4 : 0)) : -1;
+    switch (oct) {
+    case 0: fast_wave_walk_oct<STATS, 0>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 1: fast_wave_walk_oct<STATS, 1>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 2: fast_wave_walk_oct<STATS, 2>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 3: fast_wave_walk_oct<STATS, 3>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 4: fast_wave_walk_oct<STATS, 4>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 5: fast_wave_walk_oct<STATS, 5>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 6: fast_wave_walk_oct<STATS, 6>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 7: fast_wave_walk_oct<STATS, 7>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    default: fast_wave_walk_oct<STATS, -1>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    }
+}

@@ -145,15 +145,19 @@ import numpy as np
 import raytracing_amd as R
 from raytracing_amd import workloads as WL
 t = R.Tracer(0)
-sc = R.SdScene()
-sc.add_model(WL._load_obj_tris(WL.DRAGON_2426))
-sc.add_model(WL.ground_quad(y=0.0, x0=-2.0, x1=2.0, z0=-2.0, z1=2.0))
-t.upload(sc.finalize())
-t.set_camera(R.Camera(1.0, (0.05, 0.22, 0.45), 2.0, 16.0 / 9.0, (-0.006, 0.06, -0.014)))
-for trav in (R.TRAV_AUTO, R.TRAV_FAST_REFILL):
-    t.set_options(bounce_limit=8, seed=9, traversal=trav)
-    img, prim, st = t.trace(480, 270, 1, 40, want_primary=True)
-    print(trav, st.rays, st.replays, hashlib.sha256(img.tobytes()).hexdigest(), hashlib.sha256(prim.tobytes()).hexdigest())
+# a mesh on a ground quad (the frame is all scene: the path kernels generate the camera rays themselves) and the bare mesh
+# (most of the frame is sky: the camera stage queues the camera rays that meet the scene's box)
+for ground, cam in ((True, R.Camera(1.0, (0.05, 0.22, 0.45), 2.0, 16.0 / 9.0, (-0.006, 0.06, -0.014))), (False, WL.DRAGON_2426_CAMERA)):
+    sc = R.SdScene()
+    sc.add_model(WL._load_obj_tris(WL.DRAGON_2426))
+    if ground:
+        sc.add_model(WL.ground_quad(y=0.0, x0=-2.0, x1=2.0, z0=-2.0, z1=2.0))
+    t.upload(sc.finalize())
+    t.set_camera(cam)
+    for trav in (R.TRAV_AUTO, R.TRAV_FAST_REFILL):
+        t.set_options(bounce_limit=8, seed=9, traversal=trav)
+        img, prim, st = t.trace(480, 270, 1, 40, want_primary=True)
+        print(ground, trav, st.rays, st.replays, hashlib.sha256(img.tobytes()).hexdigest(), hashlib.sha256(prim.tobytes()).hexdigest())
 """
 
 
@@ -162,12 +166,14 @@ def test_results_do_not_depend_on_the_tuning():
                 {"RT_SLICE": "7", "RT_TAIL_RAYS": "3000", "RT_SLICE_QUORUM": "40", "RT_CHUNK_SAMPLES": "13"},
                 {"RT_SLICE": "1000", "RT_TAIL_RAYS": "100000000", "RT_SLICE_QUORUM": "0", "RT_EXTRA_ROUNDS": "5"},
                 {"RT_REFILL_TAIL": "0", "RT_SLICE": "33", "RT_TAIL_RAYS": "50000", "RT_CHUNK_SAMPLES": "64", "RT_EXTRA_ROUNDS": "-3"},
-                {"RT_COMPACT": "0", "RT_TAIL_RAYS": "1", "RT_SLICE_QUORUM": "63"}]
+                {"RT_COMPACT": "0", "RT_TAIL_RAYS": "1", "RT_SLICE_QUORUM": "63"},
+                # camera rays lane by lane instead of wave-synchronously, in rounds of the sliced walk
+                {"RT_WAVE_CAMERA": "0", "RT_TAIL_RAYS": "3000"}, {"RT_WAVE_CAMERA": "0", "RT_REFILL_TAIL": "0"}]
     outs = []
     for env in settings:
         r = subprocess.run([sys.executable, "-c", TUNED, ROOT], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (env, r.stderr[-2000:])
         outs.append(r.stdout.strip().splitlines())
-    assert len(outs[0]) == 2
+    assert len(outs[0]) == 4
     for env, out in zip(settings[1:], outs[1:]):
         assert out == outs[0], env
