@@ -1031,8 +1031,8 @@ RT_D void fast_wave_walk_oct(const KParams &P, const bool live, const uint32_t l
     uint32_t cur = 0u;                    // byte offset of the wave's current record
     uint32_t count = 0u;                  // jobs in the wave's list (the same in every lane)
     // (Measured and dropped: asking for the record behind this one as well -- scalar loads return in any order, so a wait for
-    // one is a wait for all: 3.5 % slower -- and records two at a time in one s_load_dwordx16: 15 % slower, the sixteen
-    // registers spill.)
+    // one is a wait for all: 3.5 % slower --; records two at a time in one s_load_dwordx16: 15 % slower, the sixteen
+    // registers spill; the record through the vector path, every lane asking for the same address: 15 % slower.)
     while (cur < n) {
         const v8f r = *(cf8ptr)(nodes + cur);
         const v4f a = {r[0], r[1], r[2], r[3]}, b = {r[4], r[5], r[6], r[7]};
