@@ -604,8 +604,9 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
         P.sub_in = ws.levels;
         P.sub_cursor = ws.levels + 1;
         P.sub_out = ws.levels + (size_t)kSubQueues * 32;
-        // one tile per wave: the tiles cost the same, and waves that start as others finish keep the chip full to the end
-        uint32_t blocks = (P.n_my_tiles + 3) / 4;
+        // one (tile, group of 64 samples) per wave: they cost the same, and waves that start as others finish keep the chip full to the end
+        const unsigned long long units = (unsigned long long)P.n_my_tiles * (unsigned long long)((s_now + 63) / 64);
+        uint32_t blocks = (uint32_t)((units + 3ull) / 4ull < 0x7FFFFFFFull ? (units + 3ull) / 4ull : 0x7FFFFFFFull);
         if (blocks > 16u * pl.full_grid)
             blocks = 16u * pl.full_grid;
         if (blocks < 1)

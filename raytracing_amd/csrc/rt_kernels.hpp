@@ -1011,15 +1011,20 @@ __global__ void __launch_bounds__(256) k_camera(const KParams P) {
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     unsigned long long n_sky = 0ull;
     const float4 root_a = P.fnodes[0], root_b = P.fnodes[1]; // the root record's box, once
-    for (uint32_t j = wave_id; j < P.n_my_tiles; j += n_waves) {
+    // One wave per (owned tile, group of 64 samples): a share of a frame has few tiles and many samples per chunk, and would
+    // leave most of the chip idle with one wave per tile.
+    const uint32_t groups = ((uint32_t)P.S + 63u) >> 6;
+    for (uint32_t jg = wave_id; jg < P.n_my_tiles * groups; jg += n_waves) {
+        const uint32_t j = jg / groups;
+        const int s0 = (int)(jg - j * groups) * 64;
         const uint32_t tile = (uint32_t)P.tile_rank + j * (uint32_t)P.tile_world;
         const uint32_t tile_y = fastdiv(tile, P.div_tiles_x);
         const int x = (int)(tile - tile_y * (uint32_t)P.tiles_x) * 8 + (int)(lane & 7u);
         const int y = (int)tile_y * 8 + (int)(lane >> 3);
         const bool live = x < P.W && y < P.H;
         const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
-        // (64 samples at a time: one word of the pixel's `deferred` mask, one reservation in the queue)
-        for (int s0 = 0; s0 < P.S; s0 += 64) {
+        // (64 samples: one word of the pixel's `deferred` mask, one reservation in the queue)
+        {
             const int sb = P.S - s0 < 64 ? P.S - s0 : 64;
             unsigned long long mask = 0ull;
             if (live) {
