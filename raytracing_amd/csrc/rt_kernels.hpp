@@ -317,7 +317,7 @@ RT_D void read_camera_record(const KParams &P, const float4 r, Path &path, uint3
 // "pixel = (pixel*(n-1) + new)/n" (Renderer/TraceMethods.cpp:59) bit for bit.
 constexpr int WALK_LANE = 0, WALK_WAVE = 1, WALK_FAST = 2, WALK_BRUTE = 3, WALK_QUEUED = 4;
 template <bool OLD, bool STATS, int WALK>
-__global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : (WALK == WALK_QUEUED && !OLD) ? 6 : 1) k_path(const KParams P) {
+__global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : WALK == WALK_QUEUED ? (OLD ? 4 : 6) : 1) k_path(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     __shared__ WaveJobs s_jobs[WALK == WALK_QUEUED ? 4 : 1]; // only the queued walk touches it
     Cnt cnt = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
@@ -413,6 +413,7 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : (WALK == WALK_QUE
             }
         }
         bool ended = false;
+        bool camera_batch = P.wave_camera != 0 && (P.level == 0 || (P.camera_stage != 0 && P.level == 1));
         // One pass = one closest-hit search and its shading.  In tail mode (the deep levels, whose few rays cannot
         // fill the chip and whose launches each last as long as their single longest walk) a lane keeps its path
         // until it ends, instead of handing it to another launch.
@@ -426,6 +427,8 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : (WALK == WALK_QUE
             cnt.rays++;
         if (WALK == WALK_WAVE && use_wave) {
             closest_hit_wave<OLD, STATS>(P, live, path.o, path.d, path.inv, hit, cnt);
+        } else if (WALK == WALK_QUEUED && camera_batch) { // camera rays of one tile and sample: neighbours
+            closest_hit_fast_wave<OLD, STATS>(P, live, lane, path.o, path.d, path.inv, hit, cnt, s_jobs[threadIdx.x >> 6]);
         } else if (WALK == WALK_QUEUED) {
             closest_hit_fast_queued<OLD, STATS>(P, live, lane, path.o, path.d, path.inv, hit, cnt, s_jobs[threadIdx.x >> 6]);
         } else {
@@ -448,6 +451,7 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : (WALK == WALK_QUE
         if (!tail)
             break;
         live = live && !ended;
+        camera_batch = false; // what a lane follows from here on is its own path
         }
         if (tail)
             continue;
@@ -884,7 +888,7 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
             }
             if constexpr (!OLD) {
                 if (camera_batch) {
-                    fast_wave_walk<STATS>(P, live, lane, path.o, path.d, path.inv, cnt, J);
+                    fast_wave_walk<false, STATS>(P, live, lane, path.o, path.d, path.inv, cnt, J);
                     if (live)
                         w.idx = n;
                 }

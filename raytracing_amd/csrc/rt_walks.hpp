@@ -1016,8 +1016,10 @@ RT_D void closest_hit_fast_queued(const KParams &P, const bool live, const uint3
 // each, through the vector-memory path the per-lane walk is bound by.  Each lane performs exactly the slab tests of its own
 // fast_walk_from, with the same arithmetic; leaves that pass are noted in the wave's list (places from a ballot: the lanes
 // are in step, no atomic is needed) with the box's entry distance, and run by resolve_jobs, the list being emptied whenever
-// the next leaf might not fit.  Flat scenes (triangles only).  Every lane of the wave must call this.
-template <bool STATS, int OCT> // OCT = sign bits (x | y<<1 | z<<2) shared by the wave's live lanes, or -1 = mixed
+// the next leaf might not fit.  A mesh object's leaf (pointer scenes) is an interior record to the wave -- its inline
+// hierarchy follows -- and to each lane that meets its box the start of a stretch in which entry distances are at least
+// the mesh box's, as in fast_walk_from.  Every lane of the wave must call this.
+template <bool OLD, bool STATS, int OCT> // OCT = sign bits (x | y<<1 | z<<2) shared by the wave's live lanes, or -1 = mixed
 RT_D void fast_wave_walk_oct(const KParams &P, const bool live, const uint32_t lane, const f3 o, const f3 d, const f3 inv, Cnt &cnt,
                              WaveJobs &J, const bool nx, const bool ny, const bool nz) {
     constexpr bool UNI = OCT >= 0;
@@ -1030,6 +1032,8 @@ RT_D void fast_wave_walk_oct(const KParams &P, const bool live, const uint32_t l
     uint32_t resume = live ? 0u : kNone; // byte offset of the next record this lane takes part in
     uint32_t cur = 0u;                    // byte offset of the wave's current record
     uint32_t count = 0u;                  // jobs in the wave's list (the same in every lane)
+    uint32_t inner_end = kNone;           // OLD: byte offset where the mesh this lane is inside ends
+    float mesh_m = 0.0f;                  // OLD: entry distance of that mesh's box
     // (Measured and dropped: asking for the record behind this one as well -- scalar loads return in any order, so a wait for
     // one is a wait for all: 3.5 % slower --; records two at a time in one s_load_dwordx16: 15 % slower, the sixteen
     // registers spill; the record through the vector path, every lane asking for the same address: 15 % slower.)
@@ -1063,11 +1067,22 @@ RT_D void fast_wave_walk_oct(const KParams &P, const bool live, const uint32_t l
         const float tmax = fminf(farz, fminf(fary, fminf(farx, inf))); // the slab test with closest = +inf
         const bool act = resume <= cur;
         const bool ok = !(tmax <= tmin);
+        if (OLD) {
+            if (cur == inner_end) {
+                mesh_m = 0.0f;
+                inner_end = kNone;
+            }
+        }
         if (STATS)
             cnt.box += act ? 1ull : 0ull;
-        resume = (act && !ok) ? skip : resume; // (a leaf's skip offset is cur + 32)
+        resume = (act && !ok) ? skip : resume; // (a primitive leaf's skip offset is cur + 32)
         const unsigned long long passed = __builtin_amdgcn_ballot_w64(act && ok);
-        if ((kind & 7u) == KIND_INTERNAL) {
+        const uint32_t k = kind & 7u;
+        if (k == KIND_INTERNAL || (OLD && k == KIND_MESH)) {
+            if (OLD && k == KIND_MESH && act && ok) {
+                mesh_m = tmin;
+                inner_end = skip;
+            }
             if (passed == 0ull) { // nobody goes in: on behind the subtree
                 cur = __builtin_amdgcn_readfirstlane(skip);
                 continue;
@@ -1077,14 +1092,21 @@ RT_D void fast_wave_walk_oct(const KParams &P, const bool live, const uint32_t l
             if (count + fresh > kJobCap) { // the list cannot take them: run what it holds (the minima per owner stay in J.key)
                 if (lane == 0)
                     J.count = count;
-                resolve_jobs<false>(P, lane, o, d, J);
+                resolve_jobs<OLD>(P, lane, o, d, J);
                 count = 0u;
             }
             if (act && ok) {
-                if (STATS)
-                    cnt.tri++;
+                const bool sphere = OLD && k == KIND_SPHERE;
+                if (STATS) {
+                    if (sphere)
+                        cnt.sph++;
+                    else
+                        cnt.tri++;
+                }
                 const uint32_t slot = kind >> 3;
-                J.jobs[count + (uint32_t)__builtin_popcountll(passed & below)] = make_uint2((lane << kJobSlotBits) | slot, __float_as_uint(tmin));
+                const float m = sphere ? fmaxf(tmin, 0.0f) : OLD ? fmaxf(tmin, mesh_m) : tmin;
+                J.jobs[count + (uint32_t)__builtin_popcountll(passed & below)] =
+                    make_uint2((lane << kJobSlotBits) | (sphere ? kJobSphere : 0u) | slot, __float_as_uint(m));
             }
             count += fresh;
         }
@@ -1092,10 +1114,10 @@ RT_D void fast_wave_walk_oct(const KParams &P, const bool live, const uint32_t l
     }
     if (lane == 0)
         J.count = count;
-    resolve_jobs<false>(P, lane, o, d, J);
+    resolve_jobs<OLD>(P, lane, o, d, J);
 }
 
-template <bool STATS>
+template <bool OLD, bool STATS>
 RT_D void fast_wave_walk(const KParams &P, const bool live, const uint32_t lane, const f3 o, const f3 d, const f3 inv, Cnt &cnt, WaveJobs &J) {
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
@@ -1104,14 +1126,33 @@ RT_D void fast_wave_walk(const KParams &P, const bool live, const uint32_t lane,
     const bool uniform = (mx == 0ull || mx == lm) && (my == 0ull || my == lm) && (mz == 0ull || mz == lm);
     const int oct = uniform ? ((mx != 0ull ? 1 : 0) | (my != 0ull ? 2 : 0) | (mz != 0ull ? 4 : 0)) : -1;
     switch (oct) {
-    case 0: fast_wave_walk_oct<STATS, 0>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
-    case 1: fast_wave_walk_oct<STATS, 1>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
-    case 2: fast_wave_walk_oct<STATS, 2>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
-    case 3: fast_wave_walk_oct<STATS, 3>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
-    case 4: fast_wave_walk_oct<STATS, 4>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
-    case 5: fast_wave_walk_oct<STATS, 5>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
-    case 6: fast_wave_walk_oct<STATS, 6>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
-    case 7: fast_wave_walk_oct<STATS, 7>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
-    default: fast_wave_walk_oct<STATS, -1>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 0: fast_wave_walk_oct<OLD, STATS, 0>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 1: fast_wave_walk_oct<OLD, STATS, 1>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 2: fast_wave_walk_oct<OLD, STATS, 2>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 3: fast_wave_walk_oct<OLD, STATS, 3>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 4: fast_wave_walk_oct<OLD, STATS, 4>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 5: fast_wave_walk_oct<OLD, STATS, 5>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 6: fast_wave_walk_oct<OLD, STATS, 6>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    case 7: fast_wave_walk_oct<OLD, STATS, 7>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    default: fast_wave_walk_oct<OLD, STATS, -1>(P, live, lane, o, d, inv, cnt, J, nx, ny, nz); break;
+    }
+}
+
+// closest_hit_fast_queued for a wave of neighbours: the wave-synchronous walk, then each lane's best of the noted tests.
+template <bool OLD, bool STATS>
+RT_D void closest_hit_fast_wave(const KParams &P, const bool live, const uint32_t lane, const f3 o, const f3 d, const f3 inv, Best &best,
+                                Cnt &cnt, WaveJobs &J) {
+    best = Best{__builtin_inff(), 0.0f, 0.0f, kNone};
+    uint32_t bpos = kNone;
+    float bm = 0.0f;
+    J.key[lane] = ~0ull;
+    if (lane == 0)
+        J.count = 0u;
+    fast_wave_walk<OLD, STATS>(P, live, lane, o, d, inv, cnt, J);
+    take_noted_result(live, lane, J, best, bpos, bm);
+    __builtin_amdgcn_wave_barrier();
+    if (live && best.ref != kNone && (bm > best.t || P.force_replay != 0)) {
+        cnt.replay++;
+        replay_ordered<OLD, STATS>(P, o, d, inv, best, cnt);
     }
 }
