@@ -1,5 +1,5 @@
 #!/bin/bash
-# Final state: smoke, the whole GPU suite, then the bench lines and the headline under rocprofv3 --kernel-trace --stats.
+# One GPU call: smoke, the whole GPU suite, then the bench lines and the headline under rocprofv3 --kernel-trace --stats.
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" || exit 1
