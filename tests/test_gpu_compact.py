@@ -147,9 +147,19 @@ from raytracing_amd import workloads as WL
 t = R.Tracer(0)
 # a mesh on a ground quad (the frame is all scene: the path kernels generate the camera rays themselves) and the bare mesh
 # (most of the frame is sky: the camera stage queues the camera rays that meet the scene's box)
-for ground, cam in ((True, R.Camera(1.0, (0.05, 0.22, 0.45), 2.0, 16.0 / 9.0, (-0.006, 0.06, -0.014))), (False, WL.DRAGON_2426_CAMERA)):
+# ... and forty big triangles stacked behind each other, each a leaf whose box every camera ray meets: a wave's 64 rays note
+# five times what its list holds, which the wave-synchronous walk has to empty on the way
+def tri(p0, p1, p2):
+    return [*p0, 0, 0, 1, 0, 0, *p1, 0, 0, 1, 0, 0, *p2, 0, 0, 1, 0, 0]
+stack = np.array([tri((-6.0, -4.0, -2.0 - 0.05 * k), (6.0, -4.0, -2.0 - 0.05 * k + 0.01 * (k % 3)), (0.0, 6.0, -2.0 - 0.05 * k)) for k in range(40)],
+                 dtype=np.float32)
+for ground, cam in ((True, R.Camera(1.0, (0.05, 0.22, 0.45), 2.0, 16.0 / 9.0, (-0.006, 0.06, -0.014))), (False, WL.DRAGON_2426_CAMERA),
+                    (None, R.Camera(1.0, (0.0, 0.0, 1.0), 2.0, 16.0 / 9.0, (0.0, 0.0, -2.0)))):
     sc = R.SdScene()
-    sc.add_model(WL._load_obj_tris(WL.DRAGON_2426))
+    if ground is None:
+        sc.add_model(stack)
+    else:
+        sc.add_model(WL._load_obj_tris(WL.DRAGON_2426))
     if ground:
         sc.add_model(WL.ground_quad(y=0.0, x0=-2.0, x1=2.0, z0=-2.0, z1=2.0))
     t.upload(sc.finalize())
@@ -174,6 +184,6 @@ def test_results_do_not_depend_on_the_tuning():
         r = subprocess.run([sys.executable, "-c", TUNED, ROOT], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (env, r.stderr[-2000:])
         outs.append(r.stdout.strip().splitlines())
-    assert len(outs[0]) == 4
+    assert len(outs[0]) == 6
     for env, out in zip(settings[1:], outs[1:]):
         assert out == outs[0], env
