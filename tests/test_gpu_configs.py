@@ -152,3 +152,34 @@ def test_flat_scene_in_the_recursive_traversal_order(tracer):
             assert np.array_equal(bits(img), bits(oimg)), (order, trav)
         res[order] = oprim
     assert np.count_nonzero(res[R.ORDER_LEFT_FIRST] != res[R.ORDER_RIGHT_FIRST]) > 100   # the order does decide the ties
+
+
+def test_wave_walked_camera_batches_against_the_oracle(tracer):
+    """The 2 426-triangle dragon on a ground quad at 1280 x 720 x 14 spp: 12.9 M pixel samples, more than the re-fill kernel
+    takes in one launch, so the first round runs in k_sliced, whose batches of fresh camera rays -- generated by the kernel
+    itself, the frame being all scene -- walk the tree wave-synchronously.  Ids, ray counts and every float of the image equal
+    the oracle's, with statistics (exact records throughout) and without (the rounds after the first step through the grid
+    records).  (Camera batches queued by the camera stage take the same walk once a round holds more than 12 Mi of them --
+    a frame of the headline's size; test_gpu_compact.py holds that path to the same bits under a lowered threshold.)"""
+    tris, sizes = objparse.load_obj(WL.DRAGON_2426)
+    W, H, S = 1280, 720, 14
+    cam = R.Camera(1.0, (0.05, 0.22, 0.45), 2.0, 16.0 / 9.0, (-0.006, 0.06, -0.014))
+    quad = WL.ground_quad(y=0.0, x0=-2.0, x1=2.0, z0=-2.0, z1=2.0)
+    sc, osc = R.SdScene(), O.SdScene()
+    sc.add_model(tris)
+    osc.add_model(tris, sizes)
+    sc.add_model(quad)
+    osc.add_model(quad, [len(quad)])
+    sc.finalize()
+    osc.finalize()
+    opt = O.make_options(bounce_limit=6, seed=21, jitter=0.001, trig=O.TRIG_POLY, threads=16)
+    oimg, oprim, ost = osc.render(oracle_camera(cam), opt, W, H, 1, S, want_primary=True)
+    assert (oprim != R.MISS).sum() > 20000
+    tracer.upload(sc)
+    tracer.set_camera(cam)
+    for stats in (True, False):
+        tracer.set_options(bounce_limit=6, seed=21, jitter=0.001, collect_stats=stats)
+        img, prim, st = tracer.trace(W, H, 1, S, want_primary=True)
+        assert np.array_equal(prim, oprim), stats
+        assert st.rays == ost.rays, stats
+        assert np.array_equal(bits(img), bits(oimg)), stats
