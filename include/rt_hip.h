@@ -219,7 +219,7 @@ int rt_set_options(rt_ctx *ctx, const rt_options *opt);
  * wavefront workspace of the context's internal pipes and the context's own image), so that those calls neither
  * allocate nor wait for an allocation; without it the first call of a size does both.  The reference's counterpart is
  * CPUImageData::resize (Renderer/TraceMethods.hpp:31-36), which sizes the trace method's buffers ahead of the loop.
- * Footprint per device: 2 pipes x (S*W*H*16 B of colours + 2 queues of (S*items + 270 336) records of 96 B), where
+ * Footprint per device: 2 pipes x (S*W*H*16 B of colours + 2 queues of (S*items + 532 480) records of 96 B), where
  * items = this context's pixels in whole 8x8 tiles and S = min(n_samples, 64, 192 Mi / items) samples per chunk --
  * 4.7 GB at 1920x1080x16, 28 GB at 3840x2160 with 23 samples per chunk.  Buffers only grow; rt_destroy releases them. */
 int rt_reserve(rt_ctx *ctx, int width, int height, int n_samples);
@@ -260,7 +260,7 @@ int rt_trace_device(rt_ctx *ctx, int width, int height, int first_sample, int n_
  * forbid hipMalloc.  It has no counterpart in the reference.  Same work and same results as rt_trace_device, but the
  * call makes no allocation of any kind (no hipMalloc / hipFree, no event or stream creation): every launch goes to the
  * context's stream, one chunk of samples after the other, in a workspace that is part of the library's code object --
- * one static array of about 107 MB per GPU the library runs on, held until the process ends.  Limit: this context's
+ * one static array of 159 MB (159 391 744 bytes) per GPU the library runs on, held until the process ends.  Limit: this context's
  * share of the frame, counted in whole 8x8 tiles, must not exceed rt_noalloc_max_pixels() = 262 144 pixels (the
  * reference's 640x360 window is 230 400); larger frames are refused with RT_ERR_INVALID_ARGUMENT.  Every context on a
  * GPU shares that GPU's workspace: calls that overlap on one GPU (two contexts, or one context whose stream was changed

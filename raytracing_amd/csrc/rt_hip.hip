@@ -68,12 +68,14 @@ namespace {
 constexpr size_t kScratchMaxItems = 256u << 10; // pixel samples per chunk = pixels of the largest frame, in whole 8x8 tiles
 constexpr size_t round256(size_t v) { return (v + 255u) & ~(size_t)255u; }
 constexpr size_t kLevelWords = (size_t)(kMaxLevels + 1) * kSubQueues * 32;
-constexpr size_t kQueueSlack = (size_t)kSubQueues * 66 * 64; // see queue_records
+constexpr uint32_t kSlackBatches = 130;                                     // batches of 64 records a sub-queue holds beyond its share, see queue_records
+constexpr size_t kQueueSlack = (size_t)kSubQueues * kSlackBatches * 64;
 constexpr size_t kScratchLevelsBytes = round256(kLevelWords * sizeof(unsigned int));
 constexpr size_t kScratchColorsBytes = round256(kScratchMaxItems * sizeof(float4));
 constexpr size_t kScratchQueueBytes = round256((kScratchMaxItems + kQueueSlack) * 6 * sizeof(float4));
 constexpr size_t kScratchDeferredBytes = round256(kScratchMaxItems * sizeof(unsigned long long));
-constexpr size_t kScratchBytes = kScratchLevelsBytes + kScratchColorsBytes + kScratchDeferredBytes + 2 * kScratchQueueBytes; // about 109 MB
+constexpr size_t kScratchBytes = kScratchLevelsBytes + kScratchColorsBytes + kScratchDeferredBytes + 2 * kScratchQueueBytes; // 159 391 744 bytes
+static_assert(kScratchBytes == 159391744, "the size stated in include/rt_hip.h");
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 // What one chunk of the wavefront tracer works in.
@@ -380,7 +382,9 @@ double root_box_coverage(const rt_ctx *ctx) {
 // Queue records a chunk of `items` pixel samples needs: a sub-queue of the next level receives the continuing paths
 // (at most 64) of every 64th batch of level 0, or of every 64th batch of each of this level's 64 sub-queues; no level
 // has more batches than level 0 has plus one partial batch per sub-queue, so (n_batches / 64 + 66) * 64 records per
-// sub-queue always suffice.
+// sub-queue suffice for the path kernels.  The camera stage appends a whole (tile, 64 samples) unit -- up to 64 batches --
+// at a time and deals the units round-robin, full groups first and the partial last group after them: a sub-queue gets at
+// most one unit of each kind beyond its share, 2 * 64 batches, hence kSlackBatches = 130.
 size_t queue_records(size_t items) { return items + kQueueSlack; }
 
 int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim, Plan &pl, const float4 *d_img_in = nullptr) {
@@ -590,7 +594,7 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
     P.S = s_now;
     P.div_per_tile = make_fastdiv(64u * (uint32_t)s_now);
     P.chunk_first = pl.first + done;
-    P.sub_cap = (((P.n_items + 63u) / 64u) / (uint32_t)kSubQueues + 66u) * 64u;
+    P.sub_cap = (((P.n_items + 63u) / 64u) / (uint32_t)kSubQueues + kSlackBatches) * 64u;
     const bool sliced = pl.sliced, queued = pl.queued, refill = pl.refill;
     const bool refill_tail = tuning().refill_tail != 0; // the sliced walk's last round is finished with lane re-fill
     const int walk = pl.walk;

@@ -1051,7 +1051,11 @@ __global__ void __launch_bounds__(256) k_camera(const KParams P) {
                 total += (uint32_t)__shfl_xor((int)total, off, 64);
             if (total == 0u)
                 continue;
-            const uint32_t q = j & (uint32_t)(kSubQueues - 1);
+            // Which sub-queue: the (tile, group) units are dealt round-robin in group-major order -- all full groups of 64
+            // samples first, the chunk's last, possibly partial group after them -- so every sub-queue receives at most one
+            // unit more than its share of either kind: its records stay within (tiles * S + 2 * 4096), which the queue's
+            // slack covers (queue_records), however few tiles a share of a frame has and however many samples its chunks hold.
+            const uint32_t q = ((uint32_t)(s0 >> 6) * P.n_my_tiles + j) & (uint32_t)(kSubQueues - 1);
             unsigned int base = 0;
             if (lane == 0)
                 base = atomicAdd(P.sub_out + q * 32u, total);

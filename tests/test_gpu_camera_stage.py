@@ -128,3 +128,39 @@ def test_chunk_of_more_than_64_samples(tracer, dragon):
         acc += part
         rays += s.rays
     assert rays == wst.rays and np.array_equal(bits(whole), bits(acc))
+
+
+@pytest.mark.parametrize("size", [(16, 8), (56, 8), (24, 16)])
+def test_few_tiles_many_samples_per_chunk(tracer, dragon, size):
+    """A share of two to seven tiles with 512 samples in ONE chunk, every camera ray past the root box: each (tile, 64
+    samples) unit of the camera stage queues up to 4096 records at once, so the units must be spread over the sub-queues
+    (one tile's eight groups landing in one sub-queue would overrun it into its neighbour's records).  Both estimators,
+    SEPARATE against FUSED against the oracle, 512 and 500 samples (a partial last group)."""
+    w, h = size
+    ps, os_ = dragon
+    cam = R.Camera(1.0, (0.0, 0.07, 0.02), 2.0, 16.0 / 9.0, (-0.006, 0.073, -0.014))   # inside the dragon's box: every camera ray gets past the root record
+    tracer.upload(ps)
+    tracer.set_camera(cam)
+    for spp in (512, 500):
+        oimg, oprim, ost = os_.render(oracle_camera(cam), O.make_options(bounce_limit=5, seed=31, trig=O.TRIG_POLY, threads=8), w, h, 1, spp,
+                                      want_primary=True)
+        for trav in (R.TRAV_FAST, R.TRAV_FAST_QUEUED, R.TRAV_FAST_REFILL):
+            for stage in (R.CAMERA_SEPARATE, R.CAMERA_FUSED):
+                tracer.set_options(bounce_limit=5, seed=31, traversal=trav, camera_stage=stage)
+                img, prim, st = tracer.trace(w, h, 1, spp, want_primary=True)
+                assert st.rays == ost.rays, (spp, trav, stage)
+                assert np.array_equal(prim, oprim) and np.array_equal(bits(img), bits(oimg)), (spp, trav, stage)
+    # the recursive estimator (four-float4 records): spheres all round the camera
+    spheres = WL.small_sphere_scene()
+    pso, oso = product_old_scene(spheres), oracle_old_scene(spheres)
+    cam2 = R.Camera(1.0, (0.0, 1.0, 4.0), 2.0, 16.0 / 9.0, (0.0, 1.0, 0.0))
+    tracer.upload(pso)
+    tracer.set_camera(cam2)
+    opt = O.make_options(bounce_limit=5, seed=32, trig=O.TRIG_POLY, accum=O.ACCUM_FORWARD, threads=8)
+    oimg, oprim, ost = oso.render(oracle_camera(cam2), opt, w, h, 1, 512, want_primary=True)
+    for trav in (R.TRAV_FAST, R.TRAV_FAST_REFILL):
+        for stage in (R.CAMERA_SEPARATE, R.CAMERA_FUSED):
+            tracer.set_options(bounce_limit=5, estimator=R.EST_OLD_RECURSIVE, seed=32, traversal=trav, camera_stage=stage)
+            img, prim, st = tracer.trace(w, h, 1, 512, want_primary=True)
+            assert st.rays == ost.rays, (trav, stage)
+            assert np.array_equal(prim, oprim) and np.array_equal(bits(img), bits(oimg)), (trav, stage)
