@@ -3,14 +3,20 @@
 
 A step is one trace pass of `spp` samples per pixel over the whole frame of the workload (the batch: W x H x spp pixel
 samples).  The K timed steps accumulate progressively into one running-mean image on the device, as the reference's
-frame loop does (Renderer/TracerImpl.cpp:9-12).  With N > 1 (launched under torch.distributed.run, one rank per GPU) the
-same K steps are shared by the ranks -- interleaved 8x8 image tiles (the default) or sample-index ranges -- and the
-render ends with ONE RCCL reduce of the W*H*4 float image onto rank 0, inside the timed region: total work is fixed,
-"scaling": "strong".
+frame loop does (Renderer/TracerImpl.cpp:9-12), and the timed region ends with the copy of the W*H*16-byte mean to
+page-locked host memory on rank 0 (the reference's setData upload, GLShader/Texture.cpp:86-91).  With N > 1 the same K steps
+are shared by N ranks, one process per GPU -- interleaved 8x8 image tiles (the default) or sample-index ranges -- and the
+render ends with ONE RCCL reduce of the W*H*4 float image onto rank 0 in front of that copy, inside the timed region:
+total work is fixed, "scaling": "strong".  `python bench.py --gpus N` starts the N ranks itself (fresh child processes,
+before this process has touched a GPU) -- the counterpart of the reference's in-call fan-out over 16 row bands
+(Renderer/TraceMethods.cpp:61-78); under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 

@@ -120,6 +120,73 @@ def test_million_triangle_field(tracer):
             assert (st.box_tests, st.tri_tests) == (ost.box_tests, ost.tri_tests)
 
 
+def test_ten_million_triangle_field(tracer):
+    """Configuration 5's large field: 23 x 23 dragons, 9 797 080 triangles in one flat list -- nine times the reference's own
+    capacity of 2^20 triangles (CPURayTrace/SimplifiedData.hpp:90) and deeper than its stack of 32 (SimplifiedData.cpp:432),
+    neither of which this build inherits.  The default walk against the per-lane reference-order walk at 480 x 270 (ids, ray
+    count, every float of the image), against the oracle on a 32 x 18 frame of the same camera, and the configuration's
+    sample-range split: two shares of the samples, each with its own sample offset, sum to the whole (to rounding: the mean
+    of two running means is not the running mean)."""
+    wl = WL.make_workload("dragon_field_k23_1080p")
+    assert len(wl.scene.tris()) == 23 * 23 * 18520 > 1 << 20
+    tracer.upload(wl.scene)
+    tracer.set_camera(wl.camera)
+    out = {}
+    for trav in (R.TRAV_FAST, R.TRAV_FAST_SLICED, R.TRAV_LANE):
+        tracer.set_options(bounce_limit=wl.bounce_limit, seed=5, collect_stats=(trav == R.TRAV_LANE), traversal=trav)
+        out[trav] = tracer.trace(480, 270, 1, 2, want_primary=True)
+    fi, fp, fs = out[R.TRAV_FAST]
+    assert (fp != R.MISS).mean() > 0.3 and len(np.unique(fp // 18520)) > 200   # most of the 529 dragons are seen
+    for trav in (R.TRAV_FAST_SLICED, R.TRAV_LANE):
+        oi, op, os2 = out[trav]
+        assert os2.rays == fs.rays and np.array_equal(op, fp) and np.array_equal(bits(oi), bits(fi)), trav
+    _image_properties(fi)
+    # the sample-range split of the configuration: shares [1, 2] and [3, 4] of four samples, RNG streams by sample offset
+    tracer.set_options(bounce_limit=wl.bounce_limit, seed=5)
+    whole, _, wst = tracer.trace(480, 270, 1, 4)
+    parts, rays = [], 0
+    for share in range(2):
+        tracer.set_options(bounce_limit=wl.bounce_limit, seed=5, sample_offset=2 * share)
+        part, _, pst = tracer.trace(480, 270, 1, 2)
+        parts.append(part)
+        rays += pst.rays
+    assert rays == wst.rays
+    assert np.array_equal(bits(parts[0]), bits(fi))
+    assert np.allclose(0.5 * (parts[0] + parts[1]), whole, rtol=1e-5, atol=1e-6)
+    # the oracle: its own builder over the 9.8 M triangles, the reference's traversal
+    osc = oracle_workload_scene(wl)
+    opt = O.make_options(bounce_limit=wl.bounce_limit, seed=5, trig=O.TRIG_POLY, threads=16)
+    oimg, oprim, ost = osc.render(oracle_camera(wl.camera), opt, 32, 18, 1, 2, want_primary=True)
+    assert (oprim != R.MISS).any()
+    for trav in (R.TRAV_FAST, R.TRAV_LANE):
+        tracer.set_options(bounce_limit=wl.bounce_limit, seed=5, collect_stats=True, traversal=trav)
+        img, prim, st = tracer.trace(32, 18, 1, 2, want_primary=True)
+        assert np.array_equal(prim, oprim) and np.array_equal(bits(img), bits(oimg)), trav
+        assert (st.rays, st.tri_hits) == (ost.rays, ost.tri_hits), trav
+        if trav == R.TRAV_LANE:
+            assert (st.box_tests, st.tri_tests) == (ost.box_tests, ost.tri_tests)
+
+
+def test_config4_as_stated_4k_256_samples(tracer, config4):
+    """Configuration 4 exactly as stated: 3840 x 2160, 256 samples per pixel, bounce limit 8 (about 6 G rays, eleven chunks),
+    one walk (the default).  No other implementation finishes this size in a test's time, so the checks are properties:
+    the ray count is that of sixteen calls' worth of the 16-sample run scaled (within the sampling noise of the paths'
+    lengths), the image is finite, non-negative, alpha in [0, 1], and equals -- bit for bit -- the same 256 samples traced
+    as 200 + 56 in two progressive calls."""
+    wl = config4
+    tracer.upload(wl.scene)
+    tracer.set_camera(wl.camera)
+    tracer.set_options(bounce_limit=wl.bounce_limit, seed=wl.seed, jitter=wl.jitter)
+    img, prim, st = tracer.trace(wl.width, wl.height, 1, 256, want_primary=True)
+    _image_properties(img)
+    assert (prim != R.MISS).mean() > 0.5
+    n = wl.width * wl.height * 256
+    assert 1.5 * n < st.rays < (wl.bounce_limit + 0.0) * n
+    tracer.trace(wl.width, wl.height, 1, 200, want_image=False)
+    img2, _, st2 = tracer.trace(wl.width, wl.height, 201, 56)
+    assert np.array_equal(bits(img), bits(img2))
+
+
 ALL_TRAVS = [R.TRAV_FAST, R.TRAV_FAST_REPLAY, R.TRAV_FAST_REFILL, R.TRAV_FAST_QUEUED, R.TRAV_FAST_INLINE, R.TRAV_FAST_SLICED,
              R.TRAV_LANE, R.TRAV_WAVE, R.TRAV_NESTED]
 
