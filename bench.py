@@ -114,16 +114,95 @@ def cpu_baseline(wl, args):
             "reference_schedule": "16 std::async row bands + shared_lock per pixel (TraceMethods.cpp:57, :61-78)"}, st, (w, h)
 
 
+def source_stamp():
+    """What the counter figures under profiles/ were measured on is recorded there as a hash of the kernel sources and of
+    the built library; this is the same pair for the tree this run loads."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "raytracing_amd", "csrc")
+    names = sorted(n for n in os.listdir(csrc) if n.endswith((".hip", ".hpp")))
+    for path in [os.path.join(csrc, n) for n in names] + [os.path.join(ROOT, "include", "rt_hip.h")]:
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    lib = os.path.join(ROOT, "raytracing_amd", "librt_hip.so")
+    so = None
+    if os.path.exists(lib):
+        with open(lib, "rb") as fh:
+            so = hashlib.sha256(fh.read()).hexdigest()[:16]
+    return {"kernel_sources_sha256": h.hexdigest()[:16], "librt_hip_sha256": so}
+
+
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` on its own: N fresh child processes, one per GPU, started BEFORE this process makes any GPU call
+    (it only counts devices); each runs this file as rank r of N, rank 0 prints the JSON line, this process waits for all
+    of them and hands their exit status on.  The counterpart of the reference's fan-out inside the trace call
+    (16 std::async row bands, Renderer/TraceMethods.cpp:61-78): the caller launches nothing."""
+    n = args.gpus
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        import torch
+        visible = torch.cuda.device_count()   # counts devices; does not initialise the GPU
+        if visible < n:
+            print(f"bench.py: --gpus {n} asked for, {visible} HIP device(s) visible: not measuring fewer GPUs under that label",
+                  file=sys.stderr)
+            return 2
+    with socket.socket() as sk:   # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    limit = time.time() + float(os.environ.get("RT_BENCH_SPAWN_TIMEOUT", "1500"))
+    rc = 0
+    pending = list(procs)
+    while pending and rc == 0:
+        for pr in list(pending):
+            code = pr.poll()
+            if code is not None:
+                pending.remove(pr)
+                if code != 0:
+                    rc = code if code > 0 else 1
+        if time.time() > limit:
+            print("bench.py: the ranks did not finish in time", file=sys.stderr)
+            rc = 3
+        if pending and rc == 0:
+            time.sleep(0.05)
+    for pr in pending:   # a rank failed (or time ran out): end the others, by their own process ids
+        pr.terminate()
+    for pr in pending:
+        try:
+            pr.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+    return rc
+
+
+def load_tracer_class():
+    """The renderer of a rank.  RT_BENCH_TRACER=module:Class swaps in another class with the Tracer's interface -- the CPU
+    tests drive the launcher and the collectives with a stand-in from tests/ and the gloo backend, no GPU in the box."""
+    spec = os.environ.get("RT_BENCH_TRACER")
+    if not spec:
+        import raytracing_amd as R
+        return R.Tracer, False
+    import importlib
+    mod, cls = spec.split(":")
+    return getattr(importlib.import_module(mod), cls), True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dragon18520_1080p")
-    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (0 = the workload's bench_spp)")
-    ap.add_argument("--split", choices=("tile", "sample"), default="tile",
-                    help="N > 1: tile = the ranks share the 8x8 tiles of every step (the default); "
-                         "sample = the ranks share the samples of every step")
+    ap.add_argument("--spp", type=int, default=0,
+                    help="samples per pixel per step (0 = the workload's bench_spp, raised until the timed steps last --min-seconds)")
+    ap.add_argument("--min-seconds", type=float, default=3.0,
+                    help="with --spp 0: samples per step are raised until the timed region lasts about this long")
+    ap.add_argument("--split", choices=("auto", "tile", "sample"), default="auto",
+                    help="N > 1: tile = the ranks share the 8x8 tiles of every step; sample = the ranks share the samples of "
+                         "every step; auto = sample for the million-triangle fields (configuration 5), tile otherwise")
     ap.add_argument("--traversal", type=int, default=4, help="RT_TRAV_* of the timed steps (4 = fast walk, 7 = with lane re-fill)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-counts", action="store_true",
@@ -134,6 +213,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="cpu_baseline sample: target seconds per timed render")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cpu_baseline: threads of schedule (ii) (0 = what the process may use)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
     if os.environ.get("RT_BENCH_WATCHDOG"):  # dump every thread's stack if the run is still going after that many seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
@@ -145,52 +228,113 @@ def main():
     import torch.distributed as dist
     from raytracing_amd import parallel as P
 
-    if not torch.cuda.is_available():
+    Tracer, stand_in = load_tracer_class()
+    on_gpu = not stand_in
+    if on_gpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the tracer has no CPU path")
     # RT_BENCH_BACKEND=gloo lets the N > 1 path be rehearsed with several ranks sharing one GPU (RCCL refuses that)
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()
-    if backend != "nccl":
+    n_dev = torch.cuda.device_count() if on_gpu else 0
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus and not (env_world == 1 and args.gpus == 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch one rank per GPU "
+                         "(torch.distributed.run --nproc-per-node == --gpus), or leave the launching to bench.py")
+    if on_gpu and backend == "nccl" and n_dev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {n_dev} HIP device(s) visible")
+    if backend != "nccl" and on_gpu:
         os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(n_dev, 1))
     rank, world, local_rank = P.init_from_env(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+
+    def device_sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     def note(msg):  # progress on stderr (a multi-minute run must not look hung)
         print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     wl = WL.make_workload(args.workload)
-    spp = args.spp or wl.bench_spp
     W, H = wl.width, wl.height
     split = args.split
-    if split == "sample" and spp % world:
-        raise SystemExit("--split sample needs spp divisible by the number of GPUs")
-    my_spp = spp // world if split == "sample" else spp          # samples per pixel this rank renders per step
-    my_pixels = W * H                                            # ... of how many pixels (tile split: its tiles')
-    tr = R.Tracer(local_rank)
+    if split == "auto":   # configuration 5 (the million-triangle fields) is stated with the sample-range split
+        split = "sample" if args.workload.startswith("dragon_field") else "tile"
+    spp = args.spp or wl.bench_spp
+    tr = Tracer(local_rank)
+    if stand_in:
+        tr.bind_workload(wl)
     tr.upload(wl.scene)
     tr.set_camera(wl.camera)
-    tr.set_stream(torch.cuda.current_stream().cuda_stream)
+    if on_gpu:
+        tr.set_stream(torch.cuda.current_stream().cuda_stream)
     img = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-    share = P.share_options(split, rank, world, samples_per_rank=my_spp * max(args.steps, args.warmup, 1))
+    # where the render's mean lands on the host (rank 0): page-locked, so the copy runs at the link's rate
+    host_img = torch.empty((H, W, 4), dtype=torch.float32, pin_memory=on_gpu) if rank == 0 else None
+    state = {"spp": spp, "my_spp": 0, "share": {}, "weight": None}
 
     def options(stats, traversal=args.traversal, bounce_limit=wl.bounce_limit):
         tr.set_options(bounce_limit=bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter,
-                       collect_stats=stats, traversal=traversal, **share)
+                       collect_stats=stats, traversal=traversal, **state["share"])
+
+    def set_spp(new_spp):
+        """Samples per pixel of a step; this rank's part of them and of the RNG's sample indices."""
+        state["spp"] = new_spp
+        state["my_spp"] = P.samples_of_rank(new_spp, rank, world) if split == "sample" else new_spp
+        state["share"] = P.share_options(split, rank, world, spp=new_spp, steps=max(args.steps, args.warmup, 1))
+        state["weight"] = P.sample_weight(rank, world, new_spp) if split == "sample" and world > 1 else None
+        options(False)
+        tr.reserve(W, H, state["my_spp"])      # set-up, untimed like the upload: the timed region never allocates
 
     # The steps of a render are issued back to back with pipelining on: the tracer overlaps the latency-bound end of one
     # chunk of samples (deep bounce levels) with the start of the next on its own streams; rt_join orders the image
     # before the reduce.
     options(False)
     tr.set_pipelining(True)
-    tr.reserve(W, H, my_spp)      # set-up, untimed like the upload: the timed region never allocates
+    set_spp(spp)
 
     def trace_pass(i):
-        tr.trace_device(W, H, 1 + i * my_spp, my_spp, img.data_ptr())
+        tr.trace_device(W, H, 1 + i * state["my_spp"], state["my_spp"], img.data_ptr())
 
     def render(n):
-        P.render(trace_pass, tr.join, img, n, split, world)
+        """One render: n passes accumulated on the device, the reduce onto rank 0 (N > 1), the mean copied to the host."""
+        P.render(trace_pass, tr.join, img, n, split, world, weight=state["weight"])
+        if rank == 0:
+            host_img.copy_(img, non_blocking=True)
+
+    grouped = dist.is_initialized()   # N > 1, or a single rank taken through the collectives (RT_FORCE_DIST=1)
+
+    def timed_render(n):
+        if grouped:
+            dist.barrier()
+        device_sync()
+        t0 = time.perf_counter()
+        render(n)
+        if grouped:
+            dist.barrier()
+        device_sync()
+        return time.perf_counter() - t0
+
+    render(args.warmup)
+    tr.sync()
+    device_sync()
+    # Samples per step: the workload's figure, raised (whole multiples, every rank alike) until the K timed steps last about
+    # --min-seconds -- a timed region of under a second is within reach of clock ramps and of the driver's own sampling.
+    if not args.spp and args.min_seconds > 0 and args.steps > 0:
+        probe = timed_render(max(min(args.steps, 4), 1)) / max(min(args.steps, 4), 1)
+        tr.sync()
+        t = torch.tensor([probe], dtype=torch.float64, device=dev)
+        if grouped:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        factor = int(min(max(-(-args.min_seconds // (float(t[0]) * args.steps)), 1), 64))
+        if factor > 1:
+            set_spp(state["spp"] * factor)
+            render(min(args.warmup, 2))
+            tr.sync()
+            device_sync()
+        note(f"a step of {spp} spp takes {float(t[0]) * 1e3:.2f} ms: {state['spp']} spp per step")
+    spp, my_spp = state["spp"], state["my_spp"]
+    my_pixels = W * H                                            # pixels this rank renders (tile split: its tiles')
 
     # work of one step: counted once, untimed, by the counting variant of the same kernels
     options(True)
@@ -201,7 +345,7 @@ def main():
     # would take minutes (the million-triangle fields)
     ref_counts = fast16 = None
     ref_spp = min(my_spp, 16)
-    if rank == 0 and not args.no_reference_counts and len(wl.scene.nodes()) < 200000:
+    if rank == 0 and on_gpu and not args.no_reference_counts and len(wl.scene.nodes()) < 200000:
         options(True)
         tr.trace_device(W, H, 1, ref_spp, img.data_ptr())
         fast16 = tr.sync()
@@ -212,19 +356,10 @@ def main():
     options(False)
     note(f"scene uploaded, work counted ({counts.rays} rays per step)")
 
-    render(args.warmup)
+    render(min(args.warmup, 1))
     tr.sync()
     note("warm-up done")
-    grouped = dist.is_initialized()   # N > 1, or a single rank taken through the collectives (RT_FORCE_DIST=1)
-    if grouped:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    render(args.steps)
-    if grouped:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_render(args.steps)
     note(f"{args.steps} timed steps in {elapsed * 1e3:.2f} ms")
     st = tr.sync()
     assert st.launches == args.steps  # st.rays: closest-hit searches of all the timed steps of this rank
@@ -262,13 +397,28 @@ def main():
         alg_bytes = traversal_bytes(counts) + image_bytes
         alg_ops = traversal_ops(counts)
         secs = kernel_ms * 1e-3
-        # hardware-counter figures of this workload, measured in separate rocprofv3 --pmc passes and kept with the
-        # profiles: HBM bytes per step (traffic), VALU issue utilisation, active lanes per VALU instruction
-        pmc = {}
+        # hardware-counter figures of this workload, measured in separate rocprofv3 --pmc passes of one trace call and kept
+        # with the profiles, together with a hash of the kernel sources (and of the library) they were measured on: figures
+        # of other kernels than the ones loaded here are not reported.  Extensive figures (bytes) are scaled from the
+        # measured call's samples per pixel to this step's.
+        pmc, pmc_note = {}, "no counter figures for this workload under profiles/"
+        stamp = source_stamp()
         ppath = os.path.join(ROOT, "profiles", "pmc_per_step.json")
-        if os.path.exists(ppath):
+        if os.path.exists(ppath) and on_gpu and world == 1:
             with open(ppath) as fh:
-                pmc = json.load(fh).get(f"{wl.name}:{my_spp}", {})
+                pfile = json.load(fh)
+            entry = pfile.get("workloads", {}).get(wl.name)
+            measured_on = pfile.get("measured_on", {})
+            if entry is not None and measured_on.get("kernel_sources_sha256") == stamp["kernel_sources_sha256"]:
+                pmc = dict(entry)
+                scale = my_spp / float(entry["spp"])
+                for key in ("hbm_bytes_per_step", "hbm_read_bytes_per_step", "hbm_write_bytes_per_step"):
+                    if pmc.get(key) is not None:
+                        pmc[key] = int(pmc[key] * scale)
+                pmc_note = "%s; bytes scaled from %d to %d samples per pixel" % (entry.get("source"), entry["spp"], my_spp)
+            elif entry is not None:
+                pmc_note = ("counter figures under profiles/ were measured on other kernel sources (%s) than the ones loaded (%s): dropped"
+                            % (measured_on.get("kernel_sources_sha256"), stamp["kernel_sources_sha256"]))
         traffic = pmc.get("hbm_bytes_per_step")
         scene_bytes = wl.scene_bytes()
         on_die = scene_bytes <= MALL_BYTES
@@ -305,7 +455,7 @@ def main():
                      # (tools/ta_probe.hip, profiles/r02_ta_probe.txt).  floor = the step's counted line accesses and misses
                      # (TCP_TOTAL_CACHE_ACCESSES, TCP_TCC_READ_REQ) at those rates; frac = floor / cycles of the step
                      "vector_memory_path": pmc.get("vector_memory_path"),
-                     "counters_from": pmc.get("source")})
+                     "counters_from": pmc_note, "loaded": stamp})
         primary = my_pixels * my_spp if wl.bounce_limit > 0 or wl.estimator != R.EST_SD_LOOP else 0
         out = {
             "metric": "Mrays/s (all bounces)", "value": rays_total / elapsed / 1e6, "unit": "Mrays/s",
@@ -315,6 +465,10 @@ def main():
             "data": "Stanford Dragon mesh bundled with the reference (data/models), no external data"
                     if wl.estimator == R.EST_SD_LOOP else "synthetic",
             "config": {"workload": wl.name, "description": wl.description, "width": W, "height": H, "spp_per_step": spp,
+                       "timed_region": "K steps accumulated into one running mean on the device" +
+                                       (", one reduce of the image onto rank 0" if world > 1 else "") +
+                                       ", the copy of the W*H*16-byte mean to page-locked host memory (rank 0); scene upload and BVH build excluded",
+                       "split": split if world > 1 else None,
                        "bounce_limit": wl.bounce_limit, "triangles": int(len(wl.scene.tris())),
                        "rays_per_step_per_gpu": int(st.rays // args.steps),
                        "traversal": "fast walk (own hierarchy over the reference's leaf boxes; hits bit-identical "
@@ -340,17 +494,17 @@ def main():
                 "tri_tests_per_ray": ref_counts.tri_tests / max(ref_counts.rays, 1),
                 "fast_walk_box_tests_per_ray": fast16.box_tests / max(fast16.rays, 1),
                 "note": "tests the reference's own traversal performs for the same rays and the same hits"}
-        if world == 1 and not args.no_extras:
+        if world == 1 and on_gpu and not args.no_extras:
             note("extra legs: camera rays alone, host-image boundary")
             # (1) camera rays alone: the same steps with bounce limit 1 (every path ends after its first search)
             options(False, bounce_limit=1)
             ksteps = max(min(args.steps, 8), 2)
             render(1)
             tr.sync()
-            torch.cuda.synchronize()
+            device_sync()
             t1 = time.perf_counter()
             render(ksteps)
-            torch.cuda.synchronize()
+            device_sync()
             t_primary = (time.perf_counter() - t1) / ksteps
             pst = tr.sync()
             t_step = elapsed / args.steps
@@ -371,9 +525,10 @@ def main():
             t_host = (time.perf_counter() - t2) / ksteps
             tr.free_host(hbuf)
             out["incl_d2h"] = {"value": hrays / ksteps / t_host / 1e6, "unit": "Mrays/s", "ms_per_step": t_host * 1e3,
-                               "note": "rt_trace, one synchronous call per step, the W*H*16-byte mean copied to page-locked "
-                                       "host memory inside the timed call (the reference's setData upload, Texture.cpp:86-91)"}
-        if world == 1 and not args.no_cpu_baseline:
+                               "note": "every step through the synchronous host-image boundary: rt_trace, one call per step, no overlap "
+                                       "between steps, the W*H*16-byte mean copied to page-locked host memory inside each call "
+                                       "(the reference's setData upload per frame, Texture.cpp:86-91)"}
+        if world == 1 and on_gpu and not args.no_cpu_baseline:
             note("CPU baseline (two renders of about %.0f s each)" % args.cpu_seconds)
             cb, ost, (cw, ch) = cpu_baseline(wl, args)
             note("CPU baseline done; checking its test counts against the GPU's reference-order walk")

@@ -8,8 +8,8 @@ threads with no communication, Renderer/TraceMethods.cpp:61-72):
 * tile split    -- rank r renders the 8x8 tiles k with k % world == r (rt_options.tile_rank/tile_world); pixels of
                    other ranks are zero, so ONE reduce(SUM) to rank 0 assembles the image and is exact (x + 0 == x).
 * sample split  -- rank r renders its own share of the samples of every pixel, with the random streams of its own
-                   sample indices (rt_options.sample_offset); ONE reduce(SUM) of the per-rank means, divided by world,
-                   gives the mean over all samples.  That is a sum-then-divide, not the reference's sequential running
+                   sample indices (rt_options.sample_offset); ONE reduce(SUM) of the per-rank means, each weighted by
+                   its share of the samples, gives the mean over all samples.  That is a sum-then-divide, not the reference's sequential running
                    mean, so it agrees with a single-GPU render to rounding, not bit for bit.
 
 A render is `n_steps` trace passes accumulated progressively into the rank's image (the reference's sampleCount
@@ -41,15 +41,23 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
-def sample_offset(rank, samples_per_rank):
-    """RNG sample-index offset of `rank` when every rank renders `samples_per_rank` samples in all: rank r draws the
-    global sample indices r * samples_per_rank + 1 .. (r + 1) * samples_per_rank."""
-    return rank * samples_per_rank
-
-
 def samples_of_rank(spp, rank, world):
-    """Samples of a pass of `spp` samples per pixel that rank `rank` renders in a sample split."""
+    """Samples of a pass of `spp` samples per pixel that rank `rank` renders in a sample split: the first spp % world
+    ranks take one more than the others."""
     return spp // world + (1 if rank < spp % world else 0)
+
+
+def sample_offset(rank, world, spp, steps=1):
+    """RNG sample-index offset of `rank` when a render is `steps` passes of `spp` samples per pixel shared by `world` ranks:
+    every rank numbers its own samples 1 .. steps * samples_of_rank(spp, rank, world) and draws the global indices that
+    follow those of the ranks before it (shares may differ by one per pass, so the offset is the sum of the preceding
+    ranks' totals, not rank times one's own)."""
+    return steps * sum(samples_of_rank(spp, q, world) for q in range(rank))
+
+
+def sample_weight(rank, world, spp):
+    """This rank's share of the samples, the weight of its mean in the combined image."""
+    return samples_of_rank(spp, rank, world) / float(spp)
 
 
 def tile_owner(x, y, width, world):
@@ -58,13 +66,14 @@ def tile_owner(x, y, width, world):
     return ((y // 8) * tiles_x + (x // 8)) % world
 
 
-def share_options(split, rank, world, samples_per_rank=0):
-    """The rt_options fields that give `rank` its share: tile_rank / tile_world, or sample_offset."""
+def share_options(split, rank, world, spp=0, steps=1):
+    """The rt_options fields that give `rank` its share: tile_rank / tile_world, or the sample offset of a render of
+    `steps` passes of `spp` samples per pixel (all ranks together)."""
     if world <= 1:
         return {}
     if split == "tile":
         return {"tile_rank": rank, "tile_world": world}
-    return {"sample_offset": sample_offset(rank, samples_per_rank)}
+    return {"sample_offset": sample_offset(rank, world, spp, steps)}
 
 
 def _reduce_sum(image, dst):
@@ -102,11 +111,12 @@ def combine_sample_split(image, dst=0, weight=None):
     return image
 
 
-def render(trace_pass, join, image, n_steps, split, world):
+def render(trace_pass, join, image, n_steps, split, world, weight=None):
     """One render on this rank: `n_steps` passes accumulated into `image`, then the one reduce.
 
     trace_pass(i): enqueue pass i (samples of step i) into `image` as a running mean, first pass restarting it;
     join(): order the image after everything enqueued (a stream-level wait is enough).
+    weight (sample split): this rank's share of the samples, sample_weight(); None = equal shares.
     In a tile split a pass writes this rank's tiles only, and on rank `dst` the previous render's reduce left the other
     ranks' pixels in `image`: the image is cleared first, so that "zero outside its tiles" holds for every render."""
     if split == "tile" and world > 1:
@@ -117,5 +127,5 @@ def render(trace_pass, join, image, n_steps, split, world):
     if split == "tile":
         combine_tile_split(image, dst=0)
     else:
-        combine_sample_split(image, dst=0)
+        combine_sample_split(image, dst=0, weight=weight)
     return image

@@ -240,6 +240,9 @@ def make_workload(name):
         sc = build_old_scene(sph).build()
         return Workload(name, sc, RTIOW_CAMERA, EST_OLD_RECURSIVE, 1920, 1080, 64, 8, seed=42, spheres=sph, bench_spp=128,
                         description="'Ray Tracing in One Weekend' final scene, 485 spheres, Lambertian / metal / dielectric")
+    if name == "cylinder_100x60":   # the smallest flat scene there is: what the CPU tests of the multi-rank path render
+        return sd_workload(name, [_load_obj_tris(CYLINDER)], DEFAULT_CAMERA, 100, 60, 2, bench_spp=2,
+                           description="SphereSingle.obj (a 124-triangle cylinder) from the reference's default camera")
     if name == "plumbing_400x225":
         sph = small_sphere_scene()
         sc = build_old_scene(sph)

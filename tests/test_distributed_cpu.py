@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 
 from helpers import O, ROOT, WL, bits, oracle_camera, oracle_sd_scene
 
-W, H, SPP, STEPS = 100, 60, 2, 2
+W, H, SPP, STEPS = 100, 60, 3, 2   # three samples per pass over two ranks: unequal shares (2 + 1)
 
 
 def _worker(rank, world, port, out_dir):
@@ -29,16 +29,19 @@ def _worker(rank, world, port, out_dir):
     cam = oracle_camera(WL.DEFAULT_CAMERA)
     for split in ("tile", "sample"):
         per_rank = P.samples_of_rank(SPP, r, w)
-        share = P.share_options(split, r, w, samples_per_rank=STEPS * per_rank)
+        share = P.share_options(split, r, w, spp=SPP, steps=STEPS)
+        if split == "sample":   # rank 0 draws the global sample indices 1 .. 4, rank 1 the indices 5, 6
+            assert share == {"sample_offset": (0, STEPS * 2)[r]} and per_rank == (2, 1)[r]
         opt = O.make_options(bounce_limit=4, seed=9, threads=2, **share)
         t = torch.zeros((H, W, 4), dtype=torch.float32)
         n = SPP if split == "tile" else per_rank
+        weight = P.sample_weight(r, w, SPP) if split == "sample" else None
 
         def trace_pass(i):
             sc.render(cam, opt, W, H, 1 + i * n, n, image=t.numpy())
 
         for attempt in range(2):   # the second render starts from what the first one's reduce left in `t`
-            P.render(trace_pass, lambda: None, t, STEPS, split, w)
+            P.render(trace_pass, lambda: None, t, STEPS, split, w, weight=weight)
             if r == 0:
                 np.save(os.path.join(out_dir, f"{split}{attempt}.npy"), t.numpy())
         if split == "tile":
@@ -58,7 +61,7 @@ def test_two_rank_partitions_over_gloo(tmp_path):
     full, _, _ = sc.render(cam, O.make_options(bounce_limit=4, seed=9), W, H, 1, STEPS * SPP)
     for attempt in range(2):
         assert np.array_equal(bits(np.load(tmp_path / f"tile{attempt}.npy")), bits(full))          # exact, both times
-        # sum-then-divide of two running means over disjoint halves of the same sample indices vs one running mean
+        # weighted sum of two running means over disjoint parts (4 + 2) of the same sample indices vs one running mean
         assert np.allclose(np.load(tmp_path / f"sample{attempt}.npy"), full, rtol=1e-5, atol=1e-6)
 
 
