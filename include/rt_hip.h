@@ -141,7 +141,11 @@ enum {
  *   TILE:   device r of n renders the 8x8 tiles k with k % n == r for all samples; the frame is put together by
  *           copying each device's tiles -- bit-identical to one device.
  *   SAMPLE: device r renders its share of the call's sample indices for every pixel into a running mean of its own;
- *           the frame is sum_r mean_r * (samples_r / samples) -- equal to one device's running mean to rounding. */
+ *           the frame is sum_r mean_r * (samples_r / samples) -- equal to one device's running mean to rounding.  The
+ *           devices' means belong to the context, so a call either restarts them (first_sample = 1) or continues the
+ *           context's own run at the same frame size (first_sample = samples so far + 1); anything else -- a mean
+ *           accumulated elsewhere handed in through d_rgba, a resize without a restart -- is refused with
+ *           RT_ERR_INVALID_ARGUMENT, where a single device would continue from the image it is given. */
 enum { RT_SPLIT_TILE = 0, RT_SPLIT_SAMPLE = 1 };
 
 /* Where the camera rays of the fast walks are made (results are the same bits either way).

@@ -159,6 +159,8 @@ def host():
         L.rth_harness_create_devices.restype = vp
         L.rth_harness_set_look_ahead.argtypes = [vp, C.c_int]
         L.rth_harness_set_look_ahead.restype = None
+        L.rth_harness_last_rays.argtypes = [vp]
+        L.rth_harness_last_rays.restype = C.c_uint64
         L.rth_harness_destroy.argtypes = [vp]
         L.rth_harness_destroy.restype = None
         for name in ("rth_harness_load", "rth_harness_render", "rth_harness_reset", "rth_harness_sample_count"):

@@ -201,6 +201,15 @@ void rth_harness_set_look_ahead(void *h, int on) {
     if (auto *b = dynamic_cast<TraceSceneHIP *>(m))
         b->lookAhead = on != 0;
 }
+// rays counted for the last frame (the trace method's lastStats)
+uint64_t rth_harness_last_rays(void *h) {
+    ITraceMethod *m = ((Harness *)h)->pipeline->getTraceMethod();
+    if (auto *a = dynamic_cast<TraceSdSceneHIP *>(m))
+        return a->lastStats.rays;
+    if (auto *b = dynamic_cast<TraceSceneHIP *>(m))
+        return b->lastStats.rays;
+    return 0;
+}
 void rth_harness_destroy(void *h) { delete (Harness *)h; }
 int rth_harness_load(void *h) { // uploader->upload(*pipeline->getLoadMethod()), Renderer.cpp:83
     return guarded([&] { ((Harness *)h)->pipeline->getLoadMethod()->load(); });

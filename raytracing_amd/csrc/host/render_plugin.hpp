@@ -273,7 +273,34 @@ template <int ESTIMATOR, class Context> class TraceHIPImpl : public ITraceMethod
         flights.push_back(Flight{sample, w, h, cam, opt, scene, image});                                   // "Scene is not loaded."
     }
 
+    // rt_trace_end reports the context's counters as accumulated since they were last read out; a frame's own share is
+    // the difference to what the frame before it reported (the counters restart whenever a synchronous call reads them).
+    rt_stats cumulative{};
+    void endFrame(const char *what, bool must) {
+        rt_stats now{};
+        const int rc = rt_trace_end(DIContext.ctx, &now);
+        if (rc != RT_OK) {
+            if (must)
+                DIContext.check(rc, what);
+            throw rc;
+        }
+        const bool restarted = now.rays < cumulative.rays;
+        const rt_stats before = restarted ? rt_stats{} : cumulative;
+        cumulative = now;
+        lastStats = rt_stats{};
+        lastStats.rays = now.rays - before.rays;
+        lastStats.box_tests = now.box_tests - before.box_tests;
+        lastStats.tri_tests = now.tri_tests - before.tri_tests;
+        lastStats.sph_tests = now.sph_tests - before.sph_tests;
+        lastStats.tri_hits = now.tri_hits - before.tri_hits;
+        lastStats.replays = now.replays - before.replays;
+    }
+
   public:
+    // Counters of the last frame.  Synchronous frames (several devices, or lookAhead off and on a multi-device context):
+    // exactly that call's, with its kernel time.  With frames computed ahead: what the device counted between this frame's
+    // hand-over and the one before it -- over a run of frames they add up to the run's total, but a single frame's figure
+    // includes whatever part of the next frames had already run; kernel_ms and launches are 0 (no timing events are taken).
     rt_stats lastStats{};
     bool lookAhead = true;
     explicit TraceHIPImpl(Context &c) : DIContext(c) {}
@@ -347,11 +374,13 @@ template <int ESTIMATOR, class Context> class TraceHIPImpl : public ITraceMethod
         DIContext.check(rt_set_options(DIContext.ctx, &opt), "rt_set_options");
         if (flights.empty())
             begin(sampleCount, w, h, cam, opt, scene);
-        if (rt_trace_end(DIContext.ctx, &lastStats) != RT_OK) {
+        try {
+            endFrame("rt_trace_end", false);
+        } catch (int) {
             // a load went in between (it drops what is in flight): this frame again, from the scene as it is now
             flights.clear();
             begin(sampleCount, w, h, cam, opt, DIContext.sceneVersion.load());
-            DIContext.check(rt_trace_end(DIContext.ctx, &lastStats), "rt_trace_end");
+            endFrame("rt_trace_end", true);
         }
         float *image = flights.front().image;
         flights.pop_front();

@@ -162,6 +162,7 @@ struct rt_ctx {
     std::vector<uint32_t *> peer_prim; // ... and for their primary-id images
     std::vector<int> kid_samples;      // sample split: samples folded into each kid's own mean since the last restart
     size_t peer_cap = 0;               // pixels the landing buffers hold
+    int multi_w = 0, multi_h = 0;      // frame size of the run the kids' means belong to
 };
 
 namespace {
@@ -1107,10 +1108,23 @@ int multi_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_out, 
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad width/height/sample range");
     const size_t px = (size_t)W * (size_t)H;
     const bool by_sample = ctx->opt.multi_split == RT_SPLIT_SAMPLE;
+    if (by_sample && first != 1) {
+        // Each device keeps the mean of ITS samples since the last restart and the frame is their weighted sum: a call can
+        // only continue the run this context itself has rendered -- not a mean accumulated elsewhere, not after a resize.
+        int so_far = 0;
+        for (int s : ctx->kid_samples)
+            so_far += s;
+        if (first != so_far + 1 || W != ctx->multi_w || H != ctx->multi_h)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT,
+                        "sample split over several devices: a call must restart the mean (first_sample = 1) or continue this "
+                        "context's own run at the same frame size (first_sample = " + std::to_string(so_far + 1) + " expected)");
+    }
     RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // the previous call's gather may still be reading the kids' frames
     if (first == 1)
         for (int &s : ctx->kid_samples)
             s = 0;
+    ctx->multi_w = W;
+    ctx->multi_h = H;
     // landing buffers on the first device
     if (px > ctx->peer_cap) {
         RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -233,6 +233,10 @@ class PluginHarness:
     def sample_count(self):
         return N.host().rth_harness_sample_count(self._h)
 
+    def last_rays(self):
+        """Rays the trace method counted for the last frame (its lastStats)."""
+        return N.host().rth_harness_last_rays(self._h)
+
     def output(self):
         w, h = C.c_uint32(), C.c_uint32()
         N.host().rth_harness_output(self._h, None, C.byref(w), C.byref(h))

@@ -62,15 +62,17 @@ def test_plugin_frames_with_and_without_look_ahead(devices):
     a resize -- the same frames with the trace method's look-ahead on and off (and over two devices, where calls are
     synchronous)."""
     product_sd_scene([WL.DRAGON_2426]).publish()
-    out = {}
+    out, rays = {}, {}
     for ahead in (False, True):
         h = R.PluginHarness(R.PluginHarness.MODE_SD, 256, 144, WL.DRAGON_2426_CAMERA, bounce_limit=4, seed=2, devices=devices)
         h.set_look_ahead(ahead)
         h.load()
         seq = []
+        rays[ahead] = []
         for _ in range(4):
             h.render()
             seq.append(h.output())
+            rays[ahead].append(h.last_rays())
         h.set_camera_position((0.05, 0.12, 0.40))      # RenderState::Dirty: the application resets the samples
         h.reset()
         for _ in range(3):
@@ -89,6 +91,13 @@ def test_plugin_frames_with_and_without_look_ahead(devices):
         assert h.sample_count() == 3
         out[ahead] = seq
         h.close()
+    # the trace method's per-frame counters: a synchronous frame reports its own rays; with frames computed ahead a frame
+    # reports what ran since the frame before it (up to two frames more), never the running total of the session
+    per_frame = rays[False]
+    assert min(per_frame) > 256 * 144 and max(per_frame) < 1.2 * min(per_frame)
+    for r in rays[True]:
+        assert 0 <= r <= 3.5 * max(per_frame)
+    assert abs(sum(rays[True]) - sum(per_frame)) <= 2.4 * max(per_frame)
     assert len(out[True]) == len(out[False]) == 11
     for a, b in zip(out[True], out[False]):
         assert a.shape == b.shape and np.array_equal(bits(a), bits(b))

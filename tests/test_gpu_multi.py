@@ -1,6 +1,7 @@
-"""Several devices behind one context (rt_create_multi), through the C ABI.  The test box has one GPU, so the device list
-names it two or three times: the host threads, the per-device shares, the peer copies and the assembly run as they would
-over distinct GPUs."""
+"""Several devices behind one context (rt_create_multi), through the C ABI.  Where the machine shows as many GPUs as a
+test asks for, the device list names distinct ones (peer copies cross xGMI); on a box with one GPU it names that one two
+or three times: the host threads, the per-device shares, the peer copies and the assembly run as they would over distinct
+GPUs."""
 import numpy as np
 import pytest
 
@@ -14,13 +15,19 @@ def scene():
     return product_sd_scene([WL.DRAGON_2426])
 
 
+def device_list(n):
+    """n distinct HIP devices when the machine has them, device 0 n times otherwise."""
+    import torch
+    return list(range(n)) if torch.cuda.device_count() >= n else [0] * n
+
+
 @pytest.mark.parametrize("n_dev", [2, 3])
 def test_tile_split_is_bit_identical_to_one_device(scene, n_dev):
     one = R.Tracer(0)
     one.upload(scene)
     one.set_camera(WL.DRAGON_2426_CAMERA)
     one.set_options(bounce_limit=6, seed=4, collect_stats=True)
-    multi = R.Tracer(devices=[0] * n_dev)
+    multi = R.Tracer(devices=device_list(n_dev))
     assert multi.device_count() == n_dev
     multi.upload(scene)
     multi.set_camera(WL.DRAGON_2426_CAMERA)
@@ -42,7 +49,7 @@ def test_sample_split_matches_one_device_to_rounding(scene):
     one.upload(scene)
     one.set_camera(WL.DRAGON_2426_CAMERA)
     one.set_options(bounce_limit=6, seed=4)
-    multi = R.Tracer(devices=[0, 0, 0])
+    multi = R.Tracer(devices=device_list(3))
     multi.upload(scene)
     multi.set_camera(WL.DRAGON_2426_CAMERA)
     multi.set_options(bounce_limit=6, seed=4, multi_split=R.SPLIT_SAMPLE)
@@ -55,13 +62,22 @@ def test_sample_split_matches_one_device_to_rounding(scene):
     b, _, bst = multi.trace(320, 180, 9, 4)                      # continues: shares 2, 1, 1
     assert ast.rays == bst.rays
     assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
+    # the devices' means belong to the context: a call that neither restarts them nor continues this very run is refused
+    with pytest.raises(R.TracerError) as e:
+        multi.trace(320, 180, 20, 2)          # samples 13 .. 19 were never rendered here
+    assert e.value.code == -1 and "first_sample = 13" in str(e.value)
+    with pytest.raises(R.TracerError):
+        multi.trace(160, 90, 13, 2)           # another frame size without a restart
+    b, _, _ = multi.trace(320, 180, 13, 1)    # the run itself goes on
+    a, _, _ = one.trace(320, 180, 13, 1)
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
     one.close()
     multi.close()
 
 
 def test_multi_device_output_on_the_device_and_refusals(scene):
     import torch
-    multi = R.Tracer(devices=[0, 0])
+    multi = R.Tracer(devices=device_list(2))
     multi.upload(scene)
     multi.set_camera(WL.DRAGON_2426_CAMERA)
     multi.set_options(bounce_limit=4, seed=9)

@@ -46,6 +46,24 @@ def test_noalloc_equals_trace_device_twice_second_smaller():
     tr.set_options(bounce_limit=8, estimator=R.EST_OLD_RECURSIVE, seed=3)
     (ai, ap, _), (bi, bp, _) = _both(tr, torch, 400, 225, 4)
     assert np.array_equal(ap, bp) and np.array_equal(bits(ai), bits(bi))
+    # what the entry point exists for: a call leaves the device's free memory as it found it -- also the first call ever of a
+    # frame size and sample count on a context that has never traced (torch.cuda.mem_get_info is hipMemGetInfo: it sees
+    # every allocation of the process, whoever made it)
+    fresh = R.Tracer(0)
+    fresh.upload(sc)
+    fresh.set_camera(WL.RTIOW_CAMERA)
+    fresh.set_stream(torch.cuda.current_stream().cuda_stream)
+    fresh.set_options(bounce_limit=8, estimator=R.EST_OLD_RECURSIVE, seed=3)
+    for (w, h, spp) in ((512, 288, 7), (200, 100, 70), (640, 400, 1)):
+        img2 = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        free_before, _ = torch.cuda.mem_get_info()
+        fresh.trace_device_noalloc(w, h, 1, spp, img2.data_ptr())
+        fresh.sync()
+        torch.cuda.synchronize()
+        free_after, _ = torch.cuda.mem_get_info()
+        assert free_after == free_before, (w, h, spp, free_before - free_after)
+    fresh.close()
     # too large for the built-in workspace: refused, nothing launched
     img = torch.zeros((1080, 1920, 4), dtype=torch.float32, device="cuda:0")
     with pytest.raises(R.TracerError) as e:
