@@ -303,7 +303,17 @@ int rt_sync(rt_ctx *ctx, rt_stats *stats);
  * at least half a step to spare --, and a word: byte offset (16 per record) of the first record after the subtree for
  * an interior record, (slot << 4) | 1 for a leaf.  leaf_records: 16 floats per triangle slot = p0, e1, e2 (nine
  * floats), pMin.x, pMin.y, reference position of the leaf (uint32 bits), pMin.z, pMax.xyz: the leaf's own box as in
- * fast_nodes, bit for bit.  n_grid_nodes is 0 for any other scene. */
+ * fast_nodes, bit for bit.  n_grid_nodes is 0 for any other scene.
+ * Flat scenes whose hierarchy is at most 16 levels deep once collapsed also get the WIDE form of the fast tree, the one
+ * the default walk of such scenes steps through: 64-byte nodes of up to eight children (a step of the walk is one trip to
+ * memory for eight slab tests).  wide_nodes, 16 uint32 per node, node 0 the root: words 0..11 the children's boxes, 8 bits
+ * per plane, as six arrays of eight bytes (lo x, hi x, lo y, hi y, lo z, hi z; child i is byte i); plane value p of axis k
+ * lies at grid unit org_k + (p << shift_k) of the grid above and the planes enclose the child's box with at least a unit
+ * and a half to spare; word 12 org_x | org_y << 16; word 13 org_z | shift_x << 16 | shift_y << 20 | shift_z << 24 |
+ * axis << 28 (the children are sorted along that axis, interior ones first, then the leaves); word 14 the index of the
+ * first interior child (interior children are consecutive nodes); word 15 first leaf slot | interior children << 24 |
+ * children << 28.  A node's leaves occupy consecutive triangle slots, and in a scene that has a wide tree the slots of
+ * tri_pos / leaf_records are numbered in that tree's order instead of the fast tree's leaf order. */
 typedef struct rt_layout_view {
     uint32_t n_fast_nodes, n_ref_nodes, n_tri_slots, n_sphere_slots;
     const float *fast_nodes;
@@ -314,6 +324,8 @@ typedef struct rt_layout_view {
     const uint32_t *grid_nodes;
     const float *leaf_records;
     float grid_origin[3], grid_step[3];
+    uint32_t n_wide_nodes;       /* 0 when the scene has no wide tree */
+    const uint32_t *wide_nodes;  /* 16 uint32 per node, see below */
     void *owner_;
 } rt_layout_view;
 int rt_layout_scene(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt_tri *tris, uint32_t n_tris,

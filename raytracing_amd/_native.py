@@ -54,7 +54,8 @@ class LayoutViewC(C.Structure):  # rt_layout_view
                 ("n_sphere_slots", C.c_uint32), ("fast_nodes", C.POINTER(C.c_float)), ("ref_nodes", C.POINTER(C.c_float)),
                 ("tri_pos", C.POINTER(C.c_float)), ("spheres", C.POINTER(C.c_float)), ("n_grid_nodes", C.c_uint32),
                 ("grid_nodes", C.POINTER(C.c_uint32)), ("leaf_records", C.POINTER(C.c_float)), ("grid_origin", C.c_float * 3),
-                ("grid_step", C.c_float * 3), ("owner_", C.c_void_p)]
+                ("grid_step", C.c_float * 3), ("n_wide_nodes", C.c_uint32), ("wide_nodes", C.POINTER(C.c_uint32)),
+                ("owner_", C.c_void_p)]
 
 
 assert C.sizeof(Node) == 36 and C.sizeof(Tri) == 100 and C.sizeof(Sphere) == 24 and C.sizeof(Material) == 24

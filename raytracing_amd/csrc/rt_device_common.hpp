@@ -26,6 +26,12 @@ constexpr uint32_t kSphereBit = 0x80000000u;
 constexpr uint32_t KIND_INTERNAL = 0, KIND_TRI = 1, KIND_MESH = 2, KIND_SPHERE = 4;
 constexpr int kSubQueues = 64;             // a level's path queue is 64 sub-queues, each with its own append counter
 constexpr int kCounterSlots = 64, kCounterStride = 16; // statistics are added into 64 slots of 16 values, summed by the host
+constexpr int kWideStack = 16;             // entries of a lane's stack in the wide walk = interior levels of the deepest wide tree the upload accepts
+constexpr uint32_t kWideWaveMinItems = 1u << 20; // wide tree: a chunk with more pixel samples than this walks its fresh camera rays wave-synchronously first
+#ifndef RT_WIDE_BURST
+#define RT_WIDE_BURST 4
+#endif
+constexpr int kWideBurst = RT_WIDE_BURST;              // nodes a lane of the wide walk visits between two looks at the wave's state
 constexpr int kMaxLevels = 64;             // bounce levels a wavefront trace can launch (bounce_limit <= 62)
 constexpr uint32_t kTailRays = 256u << 10;  // a level with no more rays than this follows every path to its end in one launch
 constexpr uint32_t kSlice = 128;            // k_sliced: records a ray is taken further per round
@@ -45,8 +51,12 @@ struct KParams {
     const float4 *fnodes; // 2 x float4 per node of the fast tree (pre-order, exact-union boxes over the reference's leaf boxes)
     const uint4 *cnodes;       // compact fast tree (flat scenes): 16 bytes per node, see SceneLayout::cn
     const float4 *leaf_boxes;  // ... and its leaves: triangle and exact box, 4 x float4 per triangle slot
+    const uint4 *wnodes;       // wide fast tree (flat scenes): 64 bytes per node of up to eight children, see build_wide
+    uint32_t wide_depth;       // ... and the entries a lane's stack needs for it (interior levels below the root, at least 1)
+    int prune;                 // the wide walk keeps a distance limit (the scene's leaves allow one, see LeafShape in scene_layout.hpp)
+    float prune_c1, prune_c2, prune_c3; // ... its constants: c1, c2, c2 W + c3
     f3 q_origin, q_step;       // ... and the grid its 16-bit planes live on
-    int compact;               // the sliced / re-fill walks go over the compact tree (2: two records per trip to memory)
+    int compact;               // the sliced / re-fill walks go over the compact tree (2: two records per trip to memory; 3: the re-fill walk goes over the wide tree)
     uint32_t slice_quorum;     // k_sliced: a wave with no more walking lanes than this ends its slice
     int wave_camera;           // k_sliced: batches of fresh camera rays take the wave-synchronous walk (fast_wave_walk)
     int refill_tail;           // k_sliced leaves a round of at most tail_rays rays to the re-fill kernel launched before it

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <type_traits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -100,6 +101,11 @@ struct rt_ctx {
     float4 *d_nodes = nullptr, *d_tri_pos = nullptr, *d_tri_nrm = nullptr, *d_spheres = nullptr, *d_mats = nullptr;
     uint32_t n_nodes = 0;
     float4 *d_cnodes = nullptr, *d_leaf_boxes = nullptr; // compact fast tree of a flat scene (SceneLayout::cn, lb)
+    float4 *d_wnodes = nullptr;                          // ... and its wide form (SceneLayout::wn)
+    bool has_wide = false;
+    uint32_t n_wide = 0, wide_depth = 1;
+    bool can_prune = false;
+    float prune_c[3] = {0.f, 0.f, 0.f};
     float q_origin[3] = {0, 0, 0}, q_step[3] = {1, 1, 1};
     bool has_compact = false;
     double compact_inflation = 1.0;
@@ -232,8 +238,10 @@ void free_scene(rt_ctx *c) {
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_cnodes) (void)hipFree(c->d_cnodes);
     if (c->d_leaf_boxes) (void)hipFree(c->d_leaf_boxes);
-    c->d_cnodes = c->d_leaf_boxes = nullptr;
-    c->has_compact = false;
+    if (c->d_wnodes) (void)hipFree(c->d_wnodes);
+    c->d_cnodes = c->d_leaf_boxes = c->d_wnodes = nullptr;
+    c->has_compact = c->has_wide = c->can_prune = false;
+    c->n_wide = 0;
     c->fast_visits = 0.0;
     c->d_nodes = c->d_tri_pos = c->d_tri_nrm = c->d_spheres = c->d_mats = nullptr;
     c->n_nodes = 0;
@@ -313,6 +321,8 @@ struct Tuning {
     int refill_tail = 1; // RT_REFILL_TAIL=0: k_sliced finishes its last round itself
     int slice_quorum = kSliceQuorum; // RT_SLICE_QUORUM
     int wave_camera = 1; // RT_WAVE_CAMERA=0: camera rays walk lane by lane like every other ray
+    int wide = 1;        // RT_WIDE=0: no walk takes the wide tree; 2: traces that collect statistics take it too
+    int prune = 1;       // RT_PRUNE=0: the wide walk keeps no distance limit
     int lds_pad = 0; // RT_LDS_PAD: bytes of unused LDS added to every path-kernel block (fewer blocks per CU: occupancy experiments)
 };
 const Tuning &tuning() {
@@ -335,6 +345,8 @@ const Tuning &tuning() {
         v.slice_quorum = (int)env("RT_SLICE_QUORUM", 0, 64, kSliceQuorum);
         v.lds_pad = (int)env("RT_LDS_PAD", 0, 40 << 10, 0);
         v.wave_camera = (int)env("RT_WAVE_CAMERA", 0, 1, 1);
+        v.wide = (int)env("RT_WIDE", 0, 2, 1);
+        v.prune = (int)env("RT_PRUNE", 0, 1, 1);
         return v;
     }();
     return t;
@@ -348,6 +360,7 @@ struct Plan {
     bool camera = false;        // the chunk starts with k_camera, the path kernels run at levels 1 .. levels
     uint32_t full_grid = 1;
     bool compact = false;       // the sliced walk steps through the compact tree
+    bool wide = false;          // ... and every ray but the fresh camera rays of scenes within the L2s through the wide tree
     size_t rec4 = 4;            // float4 per queue record
     size_t npix = 0, items_per_sample = 0;
     int W = 0, H = 0, first = 1, count = 0;
@@ -503,6 +516,12 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     // Compact tree: when the scene has one and every ray of the call starts close enough to it for the grid arithmetic's
     // margin (compact_walk_from): bounce rays start on the geometry, the camera within 32 grid extents per axis.
     P.cnodes = (const uint4 *)ctx->d_cnodes;
+    P.wnodes = (const uint4 *)ctx->d_wnodes;
+    P.wide_depth = ctx->wide_depth;
+    P.prune = ctx->can_prune && tuning().prune != 0 ? 1 : 0;
+    P.prune_c1 = ctx->prune_c[0];
+    P.prune_c2 = ctx->prune_c[1];
+    P.prune_c3 = ctx->prune_c[2];
     P.leaf_boxes = ctx->d_leaf_boxes;
     P.q_origin = mk3(ctx->q_origin[0], ctx->q_origin[1], ctx->q_origin[2]);
     P.q_step = mk3(ctx->q_step[0], ctx->q_step[1], ctx->q_step[2]);
@@ -515,12 +534,20 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
         if (!(rel > -32.0f * ext && rel < 33.0f * ext))
             pl.compact = false;
     }
+    // Wide tree: the default walk of flat scenes (RT_TRAV_FAST; the variants that name a kernel keep that kernel's walk).
+    // A chunk is then the camera stage (or not), one launch of k_sliced in which the batches of fresh camera rays are walked
+    // wave-synchronously to their ends (scenes within the L2s), and ONE launch of the re-fill kernel that follows every
+    // path to its end over the wide tree.
+    pl.wide = pl.compact && ctx->has_wide && o.traversal != RT_TRAV_FAST_SLICED && o.traversal != RT_TRAV_FAST_REFILL && o.traversal != RT_TRAV_FAST_REPLAY &&
+              tuning().wide != 0 && (!st || tuning().wide == 2);
     P.slice_quorum = (uint32_t)tuning().slice_quorum;
     // scenes within the L2s only: beyond them the scalar path, one request per wave at a time, waits far longer per record than
     // the 64 requests in flight of the lane-by-lane walk (907 k-triangle pair +19 %, 1.19 M-triangle field +8 %)
     // (which also keeps every triangle slot within the 25 bits of a job word: the wave walk notes all its leaves)
     P.wave_camera = tuning().wave_camera != 0 && ctx->scene_bytes <= kRefillSceneBytes ? 1 : 0;
     P.compact = !pl.compact ? 0 : ctx->scene_bytes > kRefillSceneBytes ? 2 : 1; // 2: two records per trip to memory
+    if (pl.wide)
+        pl.levels = 2;
     P.npix = (uint32_t)pl.npix;
     P.cpix = (uint32_t)pl.items_per_sample;
     pl.W = W;
@@ -629,6 +656,43 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
         default: hipLaunchKernelGGL((k_camera<true, true, 6>), grid, block, 0, stream, P); break;
         }
         RT_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (pl.wide) {
+        // first launch: k_sliced, whose batches of fresh camera rays walk the exact tree wave-synchronously to their ends (scenes
+        // within the L2s, and a chunk large enough to fill the chip that way); last launch: the re-fill kernel over the wide tree,
+        // every path to its end.  Without the first, the re-fill kernel takes the camera rays as well.
+        const bool by_wave = P.wave_camera != 0 && P.n_items > kWideWaveMinItems;
+        const int last = first_level + (by_wave ? 1 : 0);
+        for (int level = first_level; level <= last; level++) {
+            P.level = level;
+            P.tail = level == last ? 1 : 0;
+            P.refill_tail = 0;
+            P.tail_rays = 0u;
+            P.q_in = ws.q[level & 1];
+            P.q_out = ws.q[(level + 1) & 1];
+            P.sub_in = ws.levels + (size_t)level * kSubQueues * 32;
+            P.sub_cursor = ws.levels + (size_t)level * kSubQueues * 32 + 1;
+            P.sub_out = ws.levels + (size_t)(level + 1) * kSubQueues * 32;
+            uint32_t blocks = pl.full_grid;
+            if (level == 0 && blocks > (P.n_items / 64 + 3) / 4)
+                blocks = (P.n_items / 64 + 3) / 4;
+            if (blocks < 1)
+                blocks = 1;
+            dim3 grid(blocks);
+            const bool stats = (pl.variant & 1) != 0;
+            if (level < last) {
+                P.compact = 1;
+                if (stats) hipLaunchKernelGGL((k_sliced<false, true, 1>), grid, block, lds_pad, stream, P);
+                else hipLaunchKernelGGL((k_sliced<false, false, 1>), grid, block, lds_pad, stream, P);
+            } else {
+                P.compact = 3;
+                const unsigned stack_bytes = 4u * P.wide_depth * 64u * (unsigned)sizeof(uint32_t); // four waves' stacks
+                if (stats) hipLaunchKernelGGL((k_refill<false, true, 3, true>), grid, block, stack_bytes + lds_pad, stream, P);
+                else hipLaunchKernelGGL((k_refill<false, false, 3, true>), grid, block, stack_bytes + lds_pad, stream, P);
+            }
+            RT_HIP_CHECK(ctx, hipGetLastError());
+        }
+        return RT_OK;
     }
     for (int level = first_level; level < levels; level++) {
         P.level = level;
@@ -984,12 +1048,28 @@ int upload_layout(rt_ctx *ctx, const SceneLayout &L) {
         }
         std::memcpy(ctx->q_origin, L.q_origin, sizeof(ctx->q_origin));
         std::memcpy(ctx->q_step, L.q_step, sizeof(ctx->q_step));
+        if (L.wide) {
+            if ((rc = upload(ctx, &ctx->d_wnodes, L.wn)) != RT_OK) {
+                free_scene(ctx);
+                return rc;
+            }
+            ctx->has_wide = true;
+            ctx->n_wide = L.n_wide;
+            ctx->wide_depth = L.wide_depth > 0 ? L.wide_depth : 1u;
+            ctx->can_prune = L.prune_c1 > 0.f;
+            ctx->prune_c[0] = L.prune_c1;
+            ctx->prune_c[1] = L.prune_c2;
+            ctx->prune_c[2] = L.prune_c3;
+        }
         ctx->has_compact = true;
         ctx->compact_inflation = L.compact_inflation;
         ctx->fast_visits = L.fast_visits;
-        if (std::getenv("RT_DEBUG_LAYOUT"))
-            std::fprintf(stderr, "compact inflation %.4f expected visits %.2f fast visits %.2f scene bytes %zu\n", L.compact_inflation, L.expected_visits, L.fast_visits,
-                         (L.fn.size() + L.tp.size()) * sizeof(float4));
+        if (std::getenv("RT_DEBUG_LAYOUT")) {
+            std::fprintf(stderr, "compact inflation %.4f expected visits %.2f fast visits %.2f scene bytes %zu; wide %d: %u nodes, depth %u, visits %.2f\n",
+                         L.compact_inflation, L.expected_visits, L.fast_visits, (L.fn.size() + L.tp.size()) * sizeof(float4), (int)L.wide, L.n_wide,
+                         L.wide_depth, L.wide_visits);
+            std::fprintf(stderr, "distance limit: c1 %.3g c2 %.3g c2W+c3 %.3g, %u irregular leaves\n", L.prune_c1, L.prune_c2, L.prune_c3, L.n_irregular);
+        }
     }
     ctx->expected_visits = L.expected_visits;
     if (L.fn.size() >= 2) {
@@ -1704,6 +1784,10 @@ int rt_layout_scene(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const
         out->leaf_records = reinterpret_cast<const float *>(L->lb.data());
         std::memcpy(out->grid_origin, L->q_origin, sizeof(out->grid_origin));
         std::memcpy(out->grid_step, L->q_step, sizeof(out->grid_step));
+    }
+    if (L->wide) {
+        out->n_wide_nodes = L->n_wide;
+        out->wide_nodes = reinterpret_cast<const uint32_t *>(L->wn.data());
     }
     out->owner_ = L;
     return RT_OK;

@@ -499,11 +499,11 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : WALK == WALK_QUEU
 // What a lane of the compact walk does with a leaf record that passed its grid box, once it knows its place `j` in the
 // wave's list (compact_walk_from): the leaf goes there (resolve_jobs_compact); with no room, its exact box test and
 // triangle test run on the spot.
-template <bool STATS>
-RT_D void note_leaf(const KParams &P, const uint32_t lane, const uint32_t j, const uint32_t slot, const Path &path, WaveJobs &J, Best &best,
+template <bool STATS, class JT>
+RT_D void note_leaf(const KParams &P, const uint32_t lane, const uint32_t j, const uint32_t slot, const Path &path, JT &J, Best &best,
                     uint32_t &bpos, float &bm, Cnt &cnt) {
-    if (j < kJobCap && slot < kJobSphere) {
-        J.jobs[j] = make_uint2((lane << kJobSlotBits) | slot, 0u);
+    if (j < JT::kCap && slot < kJobSphere) {
+        J.put(j, (lane << kJobSlotBits) | slot);
         return;
     }
     float m, t, u, v;
@@ -533,20 +533,33 @@ RT_D void note_leaf(const KParams &P, const uint32_t lane, const uint32_t j, con
 // batch the wave holds, drawing a new batch from its group's cursor when that one is used up.  Same per-ray
 // arithmetic as k_path, same results.
 constexpr int kBurst = 16;
-constexpr uint32_t kServiceLanes = 24;
+#ifndef RT_SERVICE_LANES
+#define RT_SERVICE_LANES 24
+#endif
+constexpr uint32_t kServiceLanes = RT_SERVICE_LANES;
 constexpr size_t kRefillSceneBytes = 32u << 20; // 8 XCDs x 4 MB of L2
 
 // WALKS = true: the kernel finishes a round of k_sliced -- its queue holds that kernel's six-float4 records, rays in the
 // middle of their walks among them -- and follows every path to its end (tail mode).
+#ifndef RT_WIDE_WAVES
+#define RT_WIDE_WAVES 5 // waves per SIMD the wide-tree instance of k_refill is compiled for (register allocation)
+#endif
 template <bool OLD, bool STATS, int COMPACT = 0, bool WALKS = false>
-__global__ void __launch_bounds__(256) k_refill(const KParams P) {
+__global__ void __launch_bounds__(256, COMPACT == 3 ? RT_WIDE_WAVES : 1) k_refill(const KParams P) {
     constexpr size_t R4 = WALKS ? 6 : 4; // float4 per queue record
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     // Primitive tests are taken out of the walk as in closest_hit_fast_queued: lanes note them, the wave runs them together
     // before it shades (and whenever its list is about to fill up).
-    __shared__ WaveJobs s_jobs[4];
-    WaveJobs &J = s_jobs[threadIdx.x >> 6];
+    constexpr bool WIDE = COMPACT == 3;
+    using JobList = typename std::conditional<WIDE, WideJobs, WaveJobs>::type;
+    __shared__ JobList s_jobs[4];
+    JobList &J = s_jobs[threadIdx.x >> 6];
+    // the wide walk's stacks: one word per lane and level of the scene's wide tree, a wave's 64 lanes side by side (no bank
+    // conflicts), in the block's dynamic LDS (the launch sizes it: 4 waves x P.wide_depth levels x 64 lanes)
+    extern __shared__ uint32_t s_dynamic[];
+    uint32_t *const stk = s_dynamic + (WIDE ? (threadIdx.x >> 6) * (P.wide_depth * 64u) + lane : 0u);
+    uint32_t sp = 0u;
     J.key[lane] = ~0ull;
     if (lane == 0)
         J.count = 0u;
@@ -575,7 +588,8 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
     const uint32_t my_count = P.level == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sub_count, (int)my_q);
     const uint32_t my_batches = P.level == 0 ? (n_batches > my_q ? (n_batches - my_q + (uint32_t)kSubQueues - 1u) / (uint32_t)kSubQueues : 0u)
                                              : (my_count + 63u) >> 6;
-    const uint32_t n = P.n_fnodes * (COMPACT ? 16u : 32u); // a walk's position is a byte offset into the array it steps through
+    // a walk's position is a byte offset into the array it steps through (the wide walk: a node index), `n` when it is over
+    const uint32_t n = WIDE ? kWideDone : P.n_fnodes * (COMPACT ? 16u : 32u);
     // the batch the wave is handing out, and how many of its 64 items are gone (64 = none held)
     uint32_t cur_b = 0u, used = 64u;
     bool drained = my_batches == 0u; // the group's cursor has run past its last batch
@@ -593,16 +607,34 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
     uint32_t bpos = kNone;
     float bm = 0.0f;
     GridRay grid = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
+    // wide walk: the ray's distance limit is (smallest hit distance so far) * lim_a + lim_b, +inf while lim_a is +inf
+    float lim_a = __builtin_inff(), lim_b = 0.0f;
     auto start_walk = [&]() {
         path.inv = mk3(1.0f / path.d.x, 1.0f / path.d.y, 1.0f / path.d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
         if (COMPACT)
             grid = grid_ray(P, path.o, path.inv);
+        if (WIDE) {
+            const float dmax = fmaxf(fmaxf(__builtin_fabsf(path.d.x), __builtin_fabsf(path.d.y)), __builtin_fabsf(path.d.z));
+            lim_a = __builtin_inff();
+            lim_b = 0.0f;
+            if (P.prune != 0 && dmax >= 0.25f && dmax <= 1.25f) {
+                lim_a = (1.0f + 2.0f * P.prune_c2 * dmax) * 1.00001f;
+                lim_b = (P.prune_c1 / dmax + P.prune_c3) * lim_a;
+            }
+        }
         w = Walk{0u, kNone, kNone, 0.0f};
+        sp = 0u;
         best = Best{__builtin_inff(), 0.0f, 0.0f, kNone};
         bpos = kNone;
         bm = 0.0f;
         J.key[lane] = ~0ull;
         cnt.rays++;
+    };
+    // The distance limit of this lane's walk, from the closest hit it knows of: its own tests and what the noted tests that
+    // have run so far left in the wave's list (the key's upper word is the hit distance, all ones -- not a number -- for none).
+    auto walk_limit = [&]() -> float {
+        const float tau = fminf(best.t, __uint_as_float((uint32_t)(J.key[lane] >> 32)));
+        return lim_a < __builtin_inff() ? __builtin_fmaf(tau, lim_a, lim_b) : __builtin_inff();
     };
     for (;;) {
         // ---- free lanes take the next items of the held batch; a used-up batch is replaced from the group's cursor ----
@@ -642,7 +674,7 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
                         path.key = __float_as_uint(r2.w);
                         cidx = __float_as_uint(r3.x);
                         path.depth = (int)__float_as_uint(r3.y);
-                        if (WALKS && __float_as_uint(r3.z) != 0u) { // a ray in the middle of its walk (a walk never returns to record 0)
+                        if (WALKS && !WIDE && __float_as_uint(r3.z) != 0u) { // a ray in the middle of its walk (a walk never returns to record 0; the wide walk is never cut)
                             const float4 r4 = P.q_in[R4 * g + 4], r5 = P.q_in[R4 * g + 5];
                             walking = true;
                             path.inv = mk3(1.0f / path.d.x, 1.0f / path.d.y, 1.0f / path.d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
@@ -672,11 +704,18 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
             break; // nothing in flight and nothing left to hand out
         // ---- walk in bursts until enough lanes wait for service ----
         for (;;) {
-            if (COMPACT && has && w.idx < n) {
-                compact_walk_from<STATS, COMPACT == 2>(P, path.inv, grid, w.idx, kBurst, cnt,
+            if constexpr (WIDE) {
+                if (has && w.idx < n)
+                    wide_walk_from<STATS>(P, grid, w.idx, sp, stk, kWideBurst, walk_limit(), cnt,
+                                      [&](const uint32_t k) { return atomicAdd(&J.count, k); },
+                                      [&](const uint32_t j, const uint32_t slot) { note_leaf<STATS>(P, lane, j, slot, path, J, best, bpos, bm, cnt); });
+            } else if constexpr (COMPACT != 0) {
+                if (has && w.idx < n)
+                    compact_walk_from<STATS, COMPACT == 2>(P, path.inv, grid, w.idx, kBurst, cnt,
                                          [&]() { return atomicAdd(&J.count, 1u); },
                                          [&](const uint32_t j, const uint32_t slot) { note_leaf<STATS>(P, lane, j, slot, path, J, best, bpos, bm, cnt); });
-            } else if (has && w.idx < n) {
+            } else {
+                if (has && w.idx < n)
                 fast_walk_from<OLD, STATS, kBurst>(P, path.o, path.d, path.inv, w, cnt, [&](const Cand &c) {
                     if ((c.t < best.t || (c.t == best.t && c.pos < bpos)) && c.t < __builtin_inff()) {
                         best = Best{c.t, c.u, c.v, c.ref};
@@ -692,9 +731,11 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
                 });
             }
             __builtin_amdgcn_wave_barrier();
-            if (J.count + 64u * (uint32_t)kBurst / 4u > kJobCap) { // the next burst could overflow the list: run what is noted
-                if (COMPACT)
-                    resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt);
+            // the noted tests run when the next burst could overflow the list -- and, where the walk keeps a distance limit, as
+            // soon as there is a full pass of them: what they find shortens the walks that go on
+            if (J.count + JobList::kCap / 2u > JobList::kCap || (WIDE && P.prune != 0 && J.count >= 64u)) {
+                if constexpr (COMPACT != 0)
+                    resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt, WIDE ? walk_limit() : __builtin_inff());
                 else
                     resolve_jobs<OLD>(P, lane, path.o, path.d, J);
             }
@@ -707,8 +748,8 @@ __global__ void __launch_bounds__(256) k_refill(const KParams P) {
                 break;
         }
         // ---- shade the finished walks ----
-        if (COMPACT)
-            resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt);
+        if constexpr (COMPACT != 0)
+            resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt, WIDE ? walk_limit() : __builtin_inff());
         else
             resolve_jobs<OLD>(P, lane, path.o, path.d, J);
         take_noted_result(has && !(w.idx < n), lane, J, best, bpos, bm);

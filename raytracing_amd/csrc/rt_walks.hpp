@@ -621,11 +621,27 @@ constexpr uint32_t kJobSlotBits = 26;     // a job's first word: owner lane (6 b
 constexpr uint32_t kJobSphere = 1u << 25;
 
 struct WaveJobs {            // LDS of one wave
+    static constexpr uint32_t kCap = kJobCap;
     uint2 jobs[kJobCap];     // (owner lane << 26) | slot, entry distance bits
     unsigned long long key[64];
     float4 win[64];          // u, v, hit reference (Best::ref), entry distance
     float win_t[64];         // the hit distance itself (the key holds +0 for -0)
     uint32_t count;
+    RT_D void put(const uint32_t j, const uint32_t word) { jobs[j] = make_uint2(word, 0u); }
+    RT_D uint32_t word(const uint32_t j) const { return jobs[j].x; }
+};
+// The same for the wide walk, whose jobs carry no entry distance (the exact leaf test finds it) and come in smaller
+// numbers per look at the list: a quarter of the LDS, so that twice as many waves fit a compute unit.
+constexpr uint32_t kWideJobCap = 256;
+struct WideJobs {
+    static constexpr uint32_t kCap = kWideJobCap;
+    uint32_t jobs[kWideJobCap]; // (owner lane << 26) | slot
+    unsigned long long key[64];
+    float4 win[64];
+    float win_t[64];
+    uint32_t count;
+    RT_D void put(const uint32_t j, const uint32_t word) { jobs[j] = word; }
+    RT_D uint32_t word(const uint32_t j) const { return jobs[j]; }
 };
 
 // Runs the tests a wave has noted, 64 at a time, whoever noted them, and leaves each owner's best in J.key / J.win /
@@ -831,19 +847,129 @@ RT_D void compact_walk_from(const KParams &P, const f3 inv, const GridRay g, uin
     idx = at;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The wide walk (flat scenes; KParams::wnodes, laid out by build_wide).  A step is ONE 64-byte record: the boxes of up
+// to eight children on the compact tree's grid, 8 bits per plane relative to the node's own origin and scale.  Like the
+// compact walk it only has to be conservative -- the leaves that pass are noted and run through the exact leaf test and
+// the triangle test by resolve_jobs_compact -- and it visits the same leaves in some other order, which the result does
+// not depend on (closest_hit_fast).  A plane's distance along the ray is evaluated in two steps,
+//     t = p * (A * 2^shift) + (org * A + B),        A, B: the ray on the grid (GridRay), t = q * A + B for grid unit q,
+// the second rounding being what the planes' second grid unit of spare room is for.
+// The walk is depth first with a stack of one entry per level: the interior children of a node that the ray meets and
+// that are not taken at once, as (index of the node's first interior child) << 9 | (order bit) << 8 | (8-bit set of
+// children).  A node's children are sorted along one axis; a ray that runs up that axis takes them from the front of
+// the set, one that runs down from the back, so near children tend to come first.  The stack lives in LDS, one word
+// per lane and level (`stk`, the lane's column: level l at stk[64 * l]).
+constexpr uint32_t kWideDone = 0xFFFFFFFFu; // value of the walk's position once the walk is over
+
+RT_D float ubyte_f(const uint32_t w, const int i) { return (float)((w >> (8 * i)) & 0xFFu); }
+
+// Takes the walk at most `steps` nodes further.  cur: node the lane stands on (kWideDone: the walk is over); sp: entries
+// on the lane's stack.  `limit`: the walk does not enter a box the ray meets at or beyond that distance (+inf: no limit).
+// `reserve(n)` hands out n consecutive places in the wave's list of noted tests, `commit(place, slot)` notes one.
+template <bool STATS, class R, class C>
+RT_D void wide_walk_from(const KParams &P, const GridRay g, uint32_t &cur, uint32_t &sp, uint32_t *stk, int steps, const float limit,
+                         Cnt &cnt, R &&reserve, C &&commit) {
+    uint32_t at = cur, top = sp;
+    // A leaf the ray meets is noted in two halves, as in compact_walk_from: the places in the wave's list are asked for (an
+    // LDS atomic whose answer takes a hundred cycles) as soon as the node's tests are done, the jobs are written once the
+    // NEXT node has been asked for, so that the atomic's latency runs under the memory latency every step pays anyway.
+    uint32_t pend_leaves = 0u, pend_base = 0u, pend_place = 0u;
+    auto flush = [&]() {
+        while (pend_leaves != 0u) {
+            const uint32_t b = (uint32_t)__builtin_ctz(pend_leaves);
+            pend_leaves &= pend_leaves - 1u;
+            commit(pend_place++, pend_base + b);
+        }
+    };
+    while (at != kWideDone) {
+        if (steps-- == 0)
+            break;
+#ifdef RT_WIDE_DEBUG // lane use of the walk loop: thread-visits in `sph`, 64 per wave-visit in `trih`
+        if (STATS) {
+            cnt.sph++;
+            cnt.trih += (unsigned long long)__builtin_popcountll(__ballot(true)) == 0ull ? 0ull : (__lane_id() == (unsigned)__builtin_ctzll(__ballot(true)) ? 64ull : 0ull);
+        }
+#endif
+        const uint4 *rec = P.wnodes + 4 * (size_t)at;
+        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        flush();
+        // the node's frame on the grid
+        const float ox = (float)(r3.x & 0xFFFFu), oy = (float)(r3.x >> 16), oz = (float)(r3.y & 0xFFFFu);
+        const float ax = __builtin_ldexpf(g.A.x, (int)((r3.y >> 16) & 15u)), ay = __builtin_ldexpf(g.A.y, (int)((r3.y >> 20) & 15u)),
+                    az = __builtin_ldexpf(g.A.z, (int)((r3.y >> 24) & 15u));
+        const float bx = __builtin_fmaf(ox, g.A.x, g.B.x), by = __builtin_fmaf(oy, g.A.y, g.B.y), bz = __builtin_fmaf(oz, g.A.z, g.B.z);
+        const uint32_t n_int = (r3.w >> 24) & 15u, n_all = r3.w >> 28;
+        if (STATS)
+            cnt.box += n_all;
+        // near and far plane of each axis by the sign of the ray's slope on the grid: the byte arrays are picked once per
+        // node, so a child costs six conversions, six multiply-adds and the two three-way extrema
+        const bool dnx = g.A.x < 0.0f, dny = g.A.y < 0.0f, dnz = g.A.z < 0.0f;
+        const uint32_t nx0 = dnx ? r0.z : r0.x, nx1 = dnx ? r0.w : r0.y, fx0 = dnx ? r0.x : r0.z, fx1 = dnx ? r0.y : r0.w;
+        const uint32_t ny0 = dny ? r1.z : r1.x, ny1 = dny ? r1.w : r1.y, fy0 = dny ? r1.x : r1.z, fy1 = dny ? r1.y : r1.w;
+        const uint32_t nz0 = dnz ? r2.z : r2.x, nz1 = dnz ? r2.w : r2.y, fz0 = dnz ? r2.x : r2.z, fz1 = dnz ? r2.y : r2.w;
+        const float here = (r3.y & (1u << 30)) != 0u ? __builtin_inff() : limit; // nodes above a leaf the limit's bound does not cover
+        uint32_t hits = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float tnx = __builtin_fmaf(ubyte_f(i < 4 ? nx0 : nx1, i & 3), ax, bx), tfx = __builtin_fmaf(ubyte_f(i < 4 ? fx0 : fx1, i & 3), ax, bx);
+            const float tny = __builtin_fmaf(ubyte_f(i < 4 ? ny0 : ny1, i & 3), ay, by), tfy = __builtin_fmaf(ubyte_f(i < 4 ? fy0 : fy1, i & 3), ay, by);
+            const float tnz = __builtin_fmaf(ubyte_f(i < 4 ? nz0 : nz1, i & 3), az, bz), tfz = __builtin_fmaf(ubyte_f(i < 4 ? fz0 : fz1, i & 3), az, bz);
+            const float tmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 1e-6f));
+            const float tmax = fminf(fminf(tfx, tfy), fminf(tfz, here));
+            hits |= (tmax > tmin ? 1u : 0u) << i;
+        }
+        hits &= (1u << n_all) - 1u;
+        // leaves the ray meets: their places in the list asked for in one reservation, written a step later
+        pend_leaves = hits >> n_int;
+        if (pend_leaves != 0u) {
+            pend_place = reserve((uint32_t)__builtin_popcount(pend_leaves));
+            pend_base = r3.w & 0xFFFFFFu;
+        }
+        // interior children the ray meets: one now, the others on the stack
+        const uint32_t inner = hits & ((1u << n_int) - 1u);
+        const uint32_t axis = (r3.y >> 28) & 3u;
+        const bool down = axis == 0u ? dnx : axis == 1u ? dny : dnz;
+        uint32_t entry;
+        if (inner != 0u) {
+            entry = (r3.z << 9) | (down ? 256u : 0u) | inner;
+        } else if (top != 0u) {
+            top--;
+            entry = stk[64u * top];
+        } else {
+            at = kWideDone;
+            break;
+        }
+        const uint32_t set = entry & 255u;
+        const uint32_t pick = (entry & 256u) != 0u ? 31u - (uint32_t)__builtin_clz(set) : (uint32_t)__builtin_ctz(set);
+        const uint32_t rest = set & ~(1u << pick);
+        if (rest != 0u) {
+            stk[64u * top] = (entry & ~255u) | rest;
+            top++;
+        }
+        at = (entry >> 9) + pick;
+    }
+    flush();
+    cur = at;
+    sp = top;
+}
+
 // resolve_jobs for the compact walk: a job is a leaf whose grid box the owner's ray met; it runs the leaf's exact box test
 // and, if that passes, the triangle test.  `o`, `d`, `inv`: this lane's own ray.
-template <bool STATS>
-RT_D void resolve_jobs_compact(const KParams &P, const uint32_t lane, const f3 o, const f3 d, const f3 inv, WaveJobs &J, Cnt &cnt) {
+// `limit`: this lane's distance limit (wide walk; +inf elsewhere): a job whose leaf box the owner's ray enters beyond the
+// owner's limit is dropped untested.
+template <bool STATS, class JT>
+RT_D void resolve_jobs_compact(const KParams &P, const uint32_t lane, const f3 o, const f3 d, const f3 inv, JT &J, Cnt &cnt,
+                               const float limit = __builtin_inff()) {
     const float inf = __builtin_inff();
     __builtin_amdgcn_wave_barrier();
     const uint32_t noted = J.count;
-    const uint32_t n_jobs = noted < kJobCap ? noted : kJobCap;
+    const uint32_t n_jobs = noted < JT::kCap ? noted : JT::kCap;
     for (uint32_t base = 0; base < n_jobs; base += 64u) {
         const uint32_t j = base + lane;
         const bool valid = j < n_jobs;
-        const uint2 job = valid ? J.jobs[j] : make_uint2(0u, 0u);
-        const uint32_t owner = job.x >> kJobSlotBits, slot = job.x & (kJobSphere - 1u);
+        const uint32_t jobw = valid ? J.word(j) : 0u;
+        const uint32_t owner = jobw >> kJobSlotBits, slot = jobw & (kJobSphere - 1u);
         const int sel = (int)(owner << 2);
         const f3 ro = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.x))),
                           __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.y))),
@@ -854,6 +980,7 @@ RT_D void resolve_jobs_compact(const KParams &P, const uint32_t lane, const f3 o
         const f3 ri = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.x))),
                           __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.y))),
                           __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.z))));
+        const float rlimit = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(limit)));
         bool hit = false;
         unsigned long long key = ~0ull;
         float hu = 0.0f, hv = 0.0f, ht = 0.0f, hm = 0.0f;
@@ -862,7 +989,7 @@ RT_D void resolve_jobs_compact(const KParams &P, const uint32_t lane, const f3 o
             const float4 q0 = P.leaf_boxes[4 * slot], q1 = P.leaf_boxes[4 * slot + 1], q2 = P.leaf_boxes[4 * slot + 2], q3 = P.leaf_boxes[4 * slot + 3];
             if (STATS)
                 cnt.box++;
-            if (exact_leaf_entry(q2, q3, ro, ri, hm)) {
+            if (exact_leaf_entry(q2, q3, ro, ri, hm) && !(hm > rlimit)) {
                 if (STATS)
                     cnt.tri++;
                 float t, u, v;
@@ -893,7 +1020,8 @@ RT_D void resolve_jobs_compact(const KParams &P, const uint32_t lane, const f3 o
 }
 
 // Merges what resolve_jobs left for this lane into the lane's own best (which holds the tests it ran on the spot).
-RT_D void take_noted_result(const bool live, const uint32_t lane, WaveJobs &J, Best &best, uint32_t &bpos, float &bm) {
+template <class JT>
+RT_D void take_noted_result(const bool live, const uint32_t lane, JT &J, Best &best, uint32_t &bpos, float &bm) {
     const unsigned long long mine = J.key[lane];
     if (live && mine != ~0ull) {
         const float t = J.win_t[lane];

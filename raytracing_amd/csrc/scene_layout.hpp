@@ -17,7 +17,242 @@ struct SceneLayout {
     bool compact = false;
     double fast_visits = 0.0; // surface area of all fast-tree boxes / the root's: records a random ray through the root box meets
     double compact_inflation = 1.0; // surface area of all grid boxes / surface area of all exact boxes (visits of a random ray)
+    // Wide form of the fast tree, flat scenes only: one 64-byte record per node with up to eight children, see build_wide.
+    std::vector<uint4> wn;   // 4 x uint4 per node
+    uint32_t n_wide = 0, wide_depth = 0;
+    bool wide = false;
+    double wide_visits = 0.0; // surface area of all wide nodes' boxes / the root's
+    // Distance limit of the wide walk (see prune_constants): 0 in prune_c2 = the scene offers none.
+    float prune_c1 = 0.f, prune_c2 = 0.f, prune_c3 = 0.f;
+    uint32_t n_irregular = 0;
 };
+
+// ------------------------------------------------------------------------------------------------
+// How far in front of its own leaf box can a triangle test report a hit?
+//
+// The fast walk may skip a subtree whose box the ray enters at distance e only if no leaf below it can turn out to be the
+// reference's answer.  With tau the smallest hit distance found so far, a leaf can matter only as a candidate whose
+// reported hit distance t is <= tau; its own box is entered at m >= e.  So it is enough to bound m - t over ALL rays for
+// which the leaf's triangle test (sd::IntersectTriangle, SimplifiedData.cpp:269-307, evaluated in fp32 without fused
+// multiply-add) reports a hit.  With u = 2^-24, a = |e1|_inf, b = |e2|_inf, W the largest extent of the leaf box,
+// D = |d|_inf, S >= |o - p0|_inf, and the test's own guard |det| >= 1e-7 as the only lower bound on the determinant,
+// forward error analysis of the test gives (first order in u, constants rounded up)
+//     |t - t*| <= 82.7 S a b + 36.1 a b (a + b),     |u - u*| a + |v - v*| b <= (86.4 S a b + 36 a b (a + b)) D + 2.5e-7 (a + b),
+// t*, u*, v* the exact values for the stored operands, provided a b D <= 0.0277.  The exact plane point
+// p0 + u* e1 + v* e2 lies within |u - u*| a + |v - v*| b of the triangle, hence of the box, and along the axis on which the
+// ray moves fastest the box's far plane is at most (W + that distance) / D beyond t*; the slab test passed, so m is
+// below that far plane's computed distance.  Finally S <= m D + W, because the ray is inside the box at distance m and p0
+// is a corner of the triangle.  Together:
+//     m (1 - c2 D) <= t + c1 / D + c2 W + c3,    c1 = W + 3e-7 (a + b),  c2 = 170 a b,  c3 = 73 a b (a + b).
+// The walk uses twice these constants (c1, c2, c3 below are the doubled ones, maxima over the scene's REGULAR leaves) and
+// 1 / (1 - x) <= 1 + 2 x for x <= 1/2:  a subtree is skipped when  e > (tau * A + B) * (1 + 1e-5),  A = 1 + 2 c2 D,
+// B = (c1 / D + c2 W + c3) * A,  for rays with 0.25 <= D <= 1.25.  A leaf is regular when its numbers are finite,
+// a b <= 1e-3 (so c2 D <= 0.425), p0 + e1 and p0 + e2 lie inside its box, and its size is not far above the scene's
+// typical leaf (a ground quad under a mesh is not regular); nodes above an irregular leaf are never skipped.
+struct LeafShape {
+    float a, b, w; // |e1|_inf, |e2|_inf, largest extent of the leaf box
+    bool sane;     // finite, a b <= 1e-3, the triangle as stored lies inside its box
+};
+inline LeafShape leaf_shape(const rt_tri &t, const rt_node &leaf) {
+    LeafShape s{0.f, 0.f, 0.f, true};
+    for (int k = 0; k < 3; k++) {
+        const float e1 = t.pos[1][k] - t.pos[0][k], e2 = t.pos[2][k] - t.pos[0][k];
+        const float w = leaf.pmax[k] - leaf.pmin[k];
+        s.a = std::fabs(e1) > s.a ? std::fabs(e1) : s.a;
+        s.b = std::fabs(e2) > s.b ? std::fabs(e2) : s.b;
+        s.w = w > s.w ? w : s.w;
+        const double c1 = (double)t.pos[0][k] + (double)e1, c2 = (double)t.pos[0][k] + (double)e2;
+        if (!(std::fabs((double)t.pos[0][k]) < 1e15) || !(std::fabs((double)e1) < 1e15) || !(std::fabs((double)e2) < 1e15) || !(w >= 0.f) ||
+            !(w < 1e15f) || !(c1 >= leaf.pmin[k] && c1 <= leaf.pmax[k]) || !(c2 >= leaf.pmin[k] && c2 <= leaf.pmax[k]) ||
+            !((double)t.pos[0][k] >= leaf.pmin[k] && (double)t.pos[0][k] <= leaf.pmax[k]))
+            s.sane = false;
+    }
+    if (!((double)s.a * (double)s.b <= 1e-3))
+        s.sane = false;
+    return s;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The wide form of the fast tree (flat scenes).
+//
+// The binary fast tree is collapsed top-down: a wide node starts from the two children of a binary node and keeps
+// replacing the child of largest surface area by that child's own two children until it has eight (or only leaves).
+// One node is one 64-byte record, so a step of the walk is one trip to memory for eight slab tests instead of one:
+//   bytes  0..47  the children's boxes, 8 bits per plane, as six arrays of eight: lo x, hi x, lo y, hi y, lo z, hi z;
+//                 plane value p of axis k lies at grid unit  org_k + (p << shift_k)  of the 16-bit grid the compact tree
+//                 uses (SceneLayout::q_origin / q_step), and the planes enclose the child's box with TWO grid units to
+//                 spare (the compact tree's one, and one more for the second rounding of the two-step evaluation);
+//   dword 12      org_x | org_y << 16
+//   dword 13      org_z | shift_x << 16 | shift_y << 20 | shift_z << 24 | axis << 28 | (no distance limit here) << 30:
+//                 the flag marks the nodes above a leaf the limit's error bound does not cover (prune_constants)
+//   dword 14      index of the node's first interior child; interior children are consecutive records
+//   dword 15      first leaf slot (24 bits) | interior children << 24 (4 bits) | children << 28 (4 bits)
+// Children are ordered along `axis` (the axis over which their centres spread most), interior ones first, leaves after
+// them, each group by ascending centre: a ray that runs up that axis takes them from the front, one that runs down from
+// the back.  Leaf slots are numbered in the order the nodes are made, a node's leaves consecutively, and every
+// per-triangle array of the layout (tri_pos, tri_nrm, leaf_boxes) follows that numbering.
+constexpr uint32_t kWideMaxDepth = 16;        // interior levels below the root the walk's stack can hold
+constexpr uint32_t kWideMaxNodes = 1u << 23;  // a stack entry keeps a node index in 23 bits
+constexpr uint32_t kWideMaxSlots = 1u << 24;
+
+struct WideBuild {
+    std::vector<uint4> wn;
+    std::vector<uint32_t> slot_of; // binary node index of a leaf -> its slot
+    uint32_t n_slots = 0, depth = 0;
+    double area_sum = 0.0;
+    bool ok = false;
+};
+
+// bn: the binary fast tree in pre-order (fastbvh::Node); q_origin / q_step: the grid.
+// irregular: per binary node, non-zero for a leaf whose triangle the distance limit's bound does not cover (may be empty).
+inline void build_wide(const std::vector<fastbvh::Node> &bn, const float *q_origin, const float *q_step, const std::vector<uint8_t> &irregular,
+                       WideBuild &W) {
+    const uint32_t nb = (uint32_t)bn.size();
+    W.ok = false;
+    W.slot_of.assign(nb, kNone);
+    W.wn.clear();
+    if (nb == 0)
+        return;
+    // binary subtrees that hold an irregular leaf (children follow their parent in the array: one pass from the back)
+    std::vector<uint8_t> tainted(nb, 0);
+    if (!irregular.empty())
+        for (uint32_t q = nb; q-- > 0;) {
+            if (bn[q].item != 0xFFFFFFFFu)
+                tainted[q] = irregular[q];
+            else
+                tainted[q] = tainted[q + 1u] | tainted[q + 1u + bn[q + 1u].size];
+        }
+    auto half_area = [&](uint32_t c) {
+        const double x = (double)bn[c].bmax[0] - bn[c].bmin[0], y = (double)bn[c].bmax[1] - bn[c].bmin[1], z = (double)bn[c].bmax[2] - bn[c].bmin[2];
+        if (!(x >= 0.0) || !(y >= 0.0) || !(z >= 0.0))
+            return 0.0;
+        return x * y + y * z + z * x;
+    };
+    auto is_leaf = [&](uint32_t c) { return bn[c].item != 0xFFFFFFFFu; };
+    // 16-bit grid planes that enclose a coordinate with two units to spare
+    auto qlo = [&](double p, int k) {
+        const double q = std::floor((p - (double)q_origin[k]) / (double)q_step[k]) - 2.0;
+        return (int64_t)(q < 0.0 ? 0.0 : q > 65535.0 ? 65535.0 : q);
+    };
+    auto qhi = [&](double p, int k) {
+        const double q = std::ceil((p - (double)q_origin[k]) / (double)q_step[k]) + 2.0;
+        return (int64_t)(q < 0.0 ? 0.0 : q > 65535.0 ? 65535.0 : q);
+    };
+    struct Todo {
+        uint32_t q, me, depth;
+    };
+    std::vector<Todo> todo;
+    W.wn.assign(4, make_uint4(0u, 0u, 0u, 0u));
+    todo.push_back(Todo{0u, 0u, 0u});
+    uint32_t next_slot = 0, max_depth = 0;
+    const double root_area = half_area(0);
+    double area_sum = 0.0;
+    while (!todo.empty()) {
+        const Todo t = todo.back();
+        todo.pop_back();
+        if (t.depth > max_depth)
+            max_depth = t.depth;
+        if (t.depth > kWideMaxDepth)
+            return; // deeper than the walk's stack: the scene keeps its compact tree
+        area_sum += half_area(t.q);
+        uint32_t ch[8];
+        int n = 0;
+        if (is_leaf(t.q)) {
+            ch[n++] = t.q; // a scene of one triangle
+        } else {
+            ch[n++] = t.q + 1u;
+            ch[n++] = t.q + 1u + bn[t.q + 1u].size;
+            while (n < 8) {
+                int best = -1;
+                double ba = -1.0;
+                for (int i = 0; i < n; i++)
+                    if (!is_leaf(ch[i]) && half_area(ch[i]) > ba) {
+                        ba = half_area(ch[i]);
+                        best = i;
+                    }
+                if (best < 0)
+                    break;
+                const uint32_t c = ch[best];
+                ch[best] = c + 1u;
+                ch[n++] = c + 1u + bn[c + 1u].size;
+            }
+        }
+        // the axis over which the children's centres spread most; interior children first, both groups by ascending centre
+        double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) {
+                const double c = (double)bn[ch[i]].bmin[k] + (double)bn[ch[i]].bmax[k];
+                clo[k] = c < clo[k] ? c : clo[k];
+                chi[k] = c > chi[k] ? c : chi[k];
+            }
+        int axis = 0;
+        for (int k = 1; k < 3; k++)
+            if (chi[k] - clo[k] > chi[axis] - clo[axis])
+                axis = k;
+        std::stable_sort(ch, ch + n, [&](uint32_t a, uint32_t b) {
+            if (is_leaf(a) != is_leaf(b))
+                return !is_leaf(a);
+            return (double)bn[a].bmin[axis] + (double)bn[a].bmax[axis] < (double)bn[b].bmin[axis] + (double)bn[b].bmax[axis];
+        });
+        int ni = 0;
+        while (ni < n && !is_leaf(ch[ni]))
+            ni++;
+        const uint32_t child_base = (uint32_t)(W.wn.size() / 4), leaf_base = next_slot;
+        if ((size_t)child_base + (size_t)ni > kWideMaxNodes || (size_t)leaf_base + (size_t)(n - ni) > kWideMaxSlots)
+            return;
+        if (ni > 0)
+            W.wn.resize(W.wn.size() + 4 * (size_t)ni, make_uint4(0u, 0u, 0u, 0u));
+        for (int i = ni; i < n; i++)
+            W.slot_of[ch[i]] = next_slot++;
+        // planes
+        int64_t lo[8][3], hi[8][3], org[3], sh[3];
+        for (int k = 0; k < 3; k++) {
+            int64_t mn = 65535, mx = 0;
+            for (int i = 0; i < n; i++) {
+                lo[i][k] = qlo((double)bn[ch[i]].bmin[k], k);
+                hi[i][k] = qhi((double)bn[ch[i]].bmax[k], k);
+                mn = lo[i][k] < mn ? lo[i][k] : mn;
+                mx = hi[i][k] > mx ? hi[i][k] : mx;
+            }
+            org[k] = mn;
+            int64_t s = 0;
+            while (((mx - mn) + ((int64_t)1 << s) - 1) >> s > 255)
+                s++;
+            sh[k] = s;
+        }
+        uint32_t planes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // lo x (2 words), hi x, lo y, hi y, lo z, hi z
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) {
+                const int64_t l8 = (lo[i][k] - org[k]) >> sh[k];
+                const int64_t h8 = ((hi[i][k] - org[k]) + ((int64_t)1 << sh[k]) - 1) >> sh[k];
+                planes[4 * k + (i >> 2)] |= (uint32_t)l8 << (8 * (i & 3));
+                planes[4 * k + 2 + (i >> 2)] |= (uint32_t)h8 << (8 * (i & 3));
+                // the planes as the walk will place them must enclose the box with at least a unit and a half to spare
+                // (they do unless a coordinate is not finite or lies off the grid)
+                const double pl = (double)q_origin[k] + (double)(org[k] + (l8 << sh[k])) * (double)q_step[k];
+                const double ph = (double)q_origin[k] + (double)(org[k] + (h8 << sh[k])) * (double)q_step[k];
+                if (l8 < 0 || l8 > 255 || h8 < 0 || h8 > 255 || !(pl <= (double)bn[ch[i]].bmin[k] - 1.5 * (double)q_step[k]) ||
+                    !(ph >= (double)bn[ch[i]].bmax[k] + 1.5 * (double)q_step[k]))
+                    return;
+            }
+        uint4 *rec = &W.wn[4 * (size_t)t.me];
+        rec[0] = make_uint4(planes[0], planes[1], planes[2], planes[3]);
+        rec[1] = make_uint4(planes[4], planes[5], planes[6], planes[7]);
+        rec[2] = make_uint4(planes[8], planes[9], planes[10], planes[11]);
+        rec[3] = make_uint4((uint32_t)org[0] | ((uint32_t)org[1] << 16),
+                            (uint32_t)org[2] | ((uint32_t)sh[0] << 16) | ((uint32_t)sh[1] << 20) | ((uint32_t)sh[2] << 24) | ((uint32_t)axis << 28) |
+                                (tainted[t.q] ? 1u << 30 : 0u),
+                            child_base, leaf_base | ((uint32_t)ni << 24) | ((uint32_t)n << 28));
+        for (int i = ni; i-- > 0;) // first child on top: nodes are made in depth-first order
+            todo.push_back(Todo{ch[i], child_base + (uint32_t)i, t.depth + 1u});
+    }
+    W.n_slots = next_slot;
+    W.depth = max_depth;
+    W.area_sum = root_area > 0.0 ? area_sum / root_area : (double)(W.wn.size() / 4);
+    W.ok = true;
+}
+
 
 int lfail(std::string &err, int code, const std::string &msg) {
     err = msg;
@@ -145,32 +380,116 @@ int build_layout(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt
     for (auto &tree : mesh_trees)
         fastbvh::build(tree.items, tree.nodes);
 
-    // 4. Emit the fast tree, and with it the primitive arrays in fast-tree leaf order.
+    // 3b. Flat scenes: the 16-bit grid over the root box that the compact and the wide form of the fast tree place their
+    //     planes on, and the wide form's topology -- it decides the numbering of the triangle slots (see build_wide).
+    const bool flat = n_spheres == 0 && mesh_trees.empty() && !top_nodes.empty();
+    bool grid_ok = false;
+    WideBuild wide;
+    if (flat) {
+        const double lo[3] = {top_nodes[0].bmin[0], top_nodes[0].bmin[1], top_nodes[0].bmin[2]};
+        const double hi[3] = {top_nodes[0].bmax[0], top_nodes[0].bmax[1], top_nodes[0].bmax[2]};
+        grid_ok = true;
+        double ext_max = 0.0;
+        for (int k = 0; k < 3; k++)
+            ext_max = hi[k] - lo[k] > ext_max ? hi[k] - lo[k] : ext_max;
+        for (int k = 0; k < 3; k++) {
+            double ext = hi[k] - lo[k];
+            if (!(ext >= 0.0) || !(ext < 1e30))
+                grid_ok = false;
+            // A thin scene keeps a grid of at least an eighth of its largest extent on every axis: the grid arithmetic's
+            // error grows with the distance of a ray's origin in grid extents, and a camera stands off a flat scene by the
+            // scene's size, not its thickness.
+            if (ext < ext_max / 8.0)
+                ext = ext_max / 8.0;
+            float step = (float)(ext / 65530.0);
+            if (!(step > 1e-30f))
+                step = 1e-30f;
+            L.q_step[k] = step;
+            L.q_origin[k] = (float)(lo[k] - 2.0 * (double)step);
+        }
+        if (grid_ok) {
+            // the leaves' shapes: which are regular, and the distance limit's constants over those (see above LeafShape)
+            const uint32_t nbn = (uint32_t)top_nodes.size();
+            std::vector<uint8_t> irregular(nbn, 0);
+            std::vector<LeafShape> shape(nbn);
+            std::vector<float> widths, products;
+            for (uint32_t q = 0; q < nbn; q++)
+                if (top_nodes[q].item != 0xFFFFFFFFu) {
+                    const rt_node &leaf = nodes[order_of[top_items[top_nodes[q].item].id]];
+                    shape[q] = leaf_shape(tris[leaf.left], leaf);
+                    if (shape[q].sane) {
+                        widths.push_back(shape[q].w);
+                        products.push_back(shape[q].a * shape[q].b);
+                    }
+                }
+            float w_cap = 0.f, ab_cap = 0.f;
+            if (!widths.empty()) { // "not far above the typical leaf": four times the 99th percentile of the widths, sixteen of the products
+                const size_t k = (widths.size() - 1) * 99 / 100;
+                std::nth_element(widths.begin(), widths.begin() + k, widths.end());
+                std::nth_element(products.begin(), products.begin() + k, products.end());
+                w_cap = 4.f * widths[k];
+                ab_cap = 16.f * products[k];
+            }
+            double c1 = 0.0, c2 = 0.0, c3 = 0.0, wmax = 0.0;
+            uint32_t n_irr = 0, n_leaf = 0;
+            for (uint32_t q = 0; q < nbn; q++)
+                if (top_nodes[q].item != 0xFFFFFFFFu) {
+                    const LeafShape &sh = shape[q];
+                    n_leaf++;
+                    if (!sh.sane || sh.w > w_cap || sh.a * sh.b > ab_cap) {
+                        irregular[q] = 1;
+                        n_irr++;
+                        continue;
+                    }
+                    const double a = sh.a, b = sh.b;
+                    c1 = std::max(c1, 2.0 * ((double)sh.w + 3e-7 * (a + b)));
+                    c2 = std::max(c2, 340.0 * a * b);
+                    c3 = std::max(c3, 146.0 * a * b * (a + b));
+                    wmax = std::max(wmax, (double)sh.w);
+                }
+            L.n_irregular = n_irr;
+            if (n_leaf > 0 && (double)n_irr <= 0.02 * (double)n_leaf + 16.0 && c2 * 1.25 <= 0.5) {
+                L.prune_c1 = (float)(c1 * 1.000001);
+                L.prune_c2 = (float)(c2 * 1.000001);
+                L.prune_c3 = (float)((c2 * wmax + c3) * 1.000001); // c2 W + c3
+            }
+            build_wide(top_nodes, L.q_origin, L.q_step, irregular, wide);
+        }
+    }
+
+    // 4. Emit the fast tree, and with it the primitive arrays by triangle slot: slots follow the fast tree's leaf order,
+    //    or, when the scene has a wide tree, that tree's (a wide node's leaves are consecutive slots).
     std::vector<float4> &fn = L.fn, &tp = L.tp, &tn = L.tn, &sp = L.sp, &mt = L.mt;
     mt.assign(2 * (size_t)n_mats, make_float4(0.f, 0.f, 0.f, 0.f));
-    tp.reserve(3 * (size_t)n_tris);
-    tn.reserve(3 * (size_t)n_tris);
+    size_t n_tri_leaves = 0;
+    for (uint32_t p = 0; p < m; p++)
+        n_tri_leaves += nodes[order_of[p]].flags == RT_NODE_LEAF ? 1u : 0u;
+    tp.assign(3 * n_tri_leaves, make_float4(0.f, 0.f, 0.f, 0.f));
+    tn.assign(3 * n_tri_leaves, make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<uint32_t> slot_of(m, 0); // reference position of a leaf -> its triangle / sphere slot
     uint32_t tri_slots = 0, sph_slots = 0;
     auto push_node = [&](const float *bmin, const float *bmax, uint32_t skip_index, uint32_t word) {
         fn.push_back(make_float4(bmin[0], bmin[1], bmin[2], bmax[0]));
         fn.push_back(make_float4(bmax[1], bmax[2], u2f(skip_index * 32u), u2f(word)));
     };
-    auto emit_tri = [&](uint32_t p) -> int { // p = reference position of the leaf
+    auto emit_tri = [&](uint32_t p, uint32_t slot) -> int { // p = reference position of the leaf
         const rt_node &nd = nodes[order_of[p]];
         const rt_tri &t = tris[nd.left];
         if (n_mats && t.mat >= n_mats)
             return RT_ERR_BAD_SCENE;
-        slot_of[p] = tri_slots++;
+        if ((size_t)slot >= n_tri_leaves)
+            return RT_ERR_BAD_SCENE;
+        slot_of[p] = slot;
+        tri_slots++;
         // edges are the same fp32 subtractions the triangle test starts with (SimplifiedData.cpp:272-273)
         const float e1x = t.pos[1][0] - t.pos[0][0], e1y = t.pos[1][1] - t.pos[0][1], e1z = t.pos[1][2] - t.pos[0][2];
         const float e2x = t.pos[2][0] - t.pos[0][0], e2y = t.pos[2][1] - t.pos[0][1], e2z = t.pos[2][2] - t.pos[0][2];
-        tp.push_back(make_float4(t.pos[0][0], t.pos[0][1], t.pos[0][2], e1x));
-        tp.push_back(make_float4(e1y, e1z, e2x, e2y));
-        tp.push_back(make_float4(e2z, u2f(nd.left), u2f((uint32_t)t.mat), u2f(p)));
-        tn.push_back(make_float4(t.nrm[0][0], t.nrm[0][1], t.nrm[0][2], t.nrm[1][0]));
-        tn.push_back(make_float4(t.nrm[1][1], t.nrm[1][2], t.nrm[2][0], t.nrm[2][1]));
-        tn.push_back(make_float4(t.nrm[2][2], 0.f, 0.f, 0.f));
+        tp[3 * (size_t)slot] = make_float4(t.pos[0][0], t.pos[0][1], t.pos[0][2], e1x);
+        tp[3 * (size_t)slot + 1] = make_float4(e1y, e1z, e2x, e2y);
+        tp[3 * (size_t)slot + 2] = make_float4(e2z, u2f(nd.left), u2f((uint32_t)t.mat), u2f(p));
+        tn[3 * (size_t)slot] = make_float4(t.nrm[0][0], t.nrm[0][1], t.nrm[0][2], t.nrm[1][0]);
+        tn[3 * (size_t)slot + 1] = make_float4(t.nrm[1][1], t.nrm[1][2], t.nrm[2][0], t.nrm[2][1]);
+        tn[3 * (size_t)slot + 2] = make_float4(t.nrm[2][2], 0.f, 0.f, 0.f);
         return RT_OK;
     };
     const uint32_t n_top = (uint32_t)top_nodes.size();
@@ -185,7 +504,7 @@ int build_layout(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt
         const uint32_t p = top_items[fnode.item].id;
         const rt_node &nd = nodes[order_of[p]];
         if (nd.flags == RT_NODE_LEAF) {
-            if (emit_tri(p) != RT_OK)
+            if (emit_tri(p, wide.ok ? wide.slot_of[q] : tri_slots) != RT_OK)
                 return lfail(err, RT_ERR_BAD_SCENE, "triangle material out of range");
             push_node(fnode.bmin, fnode.bmax, 0u, (slot_of[p] << 3) | KIND_TRI);
         } else if (nd.flags == RT_NODE_SPHERE) {
@@ -208,7 +527,7 @@ int build_layout(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt
                     word = (base + j + 1u + tree.nodes[j + 1].size) * 32u;
                 } else {
                     const uint32_t pj = tree.items[in.item].id;
-                    if (emit_tri(pj) != RT_OK)
+                    if (emit_tri(pj, tri_slots) != RT_OK)
                         return lfail(err, RT_ERR_BAD_SCENE, "triangle material out of range");
                     word = (slot_of[pj] << 3) | KIND_TRI;
                 }
@@ -261,30 +580,12 @@ int build_layout(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt
         const double ra = area(nodes[root]);
         L.expected_visits = ra > 0.0 ? sum / ra : (double)m;
     }
-    // 6. The compact form of the fast tree (see SceneLayout::cn).
+    // 6. The compact form of the fast tree (see SceneLayout::cn), on the grid of step 3b.
     L.compact = false;
-    if (n_spheres == 0 && mesh_trees.empty() && n_fast > 0 && tri_slots < (1u << 28)) {
+    if (flat && n_fast > 0 && tri_slots < (1u << 28)) {
         const float4 ra = fn[0], rb = fn[1];
         const double lo[3] = {ra.x, ra.y, ra.z}, hi[3] = {ra.w, rb.x, rb.y};
-        bool ok = true;
-        double ext_max = 0.0;
-        for (int k = 0; k < 3; k++)
-            ext_max = hi[k] - lo[k] > ext_max ? hi[k] - lo[k] : ext_max;
-        for (int k = 0; k < 3; k++) {
-            double ext = hi[k] - lo[k];
-            if (!(ext >= 0.0) || !(ext < 1e30))
-                ok = false;
-            // A thin scene keeps a grid of at least an eighth of its largest extent on every axis: the grid arithmetic's
-            // error grows with the distance of a ray's origin in grid extents, and a camera stands off a flat scene by the
-            // scene's size, not its thickness.
-            if (ext < ext_max / 8.0)
-                ext = ext_max / 8.0;
-            float step = (float)(ext / 65530.0);
-            if (!(step > 1e-30f))
-                step = 1e-30f;
-            L.q_step[k] = step;
-            L.q_origin[k] = (float)(lo[k] - 2.0 * (double)step);
-        }
+        bool ok = grid_ok;
         if (ok) {
             L.cn.assign((size_t)n_fast + 1, make_uint4(0u, 0u, 0u, 0u)); // one unused record at the end: the walk loads records in twos
             L.lb.assign(4 * (size_t)tri_slots, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -342,6 +643,15 @@ int build_layout(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt
                 L.lb.clear();
             }
         }
+    }
+    // 7. The wide form: its records were made in step 3b; it needs the compact form's leaf records (by slot).
+    L.wide = false;
+    if (L.compact && wide.ok && wide.n_slots == tri_slots) {
+        L.wn.swap(wide.wn);
+        L.n_wide = (uint32_t)(L.wn.size() / 4);
+        L.wide_depth = wide.depth;
+        L.wide_visits = wide.area_sum;
+        L.wide = true;
     }
     L.n_ref = m;
     L.n_fast = n_fast;

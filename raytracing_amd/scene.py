@@ -171,7 +171,7 @@ def device_layout(scene):
     """What rt_upload_scene lays out for the device, as numpy arrays (host-only; rt_layout_scene): a dict with
     `fast` and `ref` node records (n, 8) float32, `tri_pos` (slots, 12) and `spheres` (slots, 8); for flat scenes also
     `grid` (n, 4) uint32, `leaf_records` (slots, 16) float32, `grid_origin` and `grid_step` (3,) float32 (`grid` is
-    empty for other scenes)."""
+    empty for other scenes), and `wide` (nodes, 16) uint32, the wide form of the fast tree (empty when there is none)."""
     nodes, tris, sph, mats = scene.nodes(), scene.tris(), scene.spheres(), scene.materials()
 
     def ptr(a):
@@ -191,6 +191,8 @@ def device_layout(scene):
            "grid": (np.ctypeslib.as_array(v.grid_nodes, shape=(v.n_grid_nodes, 4)).copy() if v.n_grid_nodes
                     else np.zeros((0, 4), dtype=np.uint32)),
            "leaf_records": grab(v.leaf_records, v.n_tri_slots if v.n_grid_nodes else 0, 16),
-           "grid_origin": np.array(list(v.grid_origin), dtype=np.float32), "grid_step": np.array(list(v.grid_step), dtype=np.float32)}
+           "grid_origin": np.array(list(v.grid_origin), dtype=np.float32), "grid_step": np.array(list(v.grid_step), dtype=np.float32),
+           "wide": (np.ctypeslib.as_array(v.wide_nodes, shape=(v.n_wide_nodes, 16)).copy() if v.n_wide_nodes
+                    else np.zeros((0, 16), dtype=np.uint32))}
     N.hip().rt_layout_free(C.byref(v))
     return out

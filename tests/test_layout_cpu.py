@@ -108,10 +108,14 @@ def check_scene(scene):
         # the leaf keeps the reference's own leaf box, bit for bit
         assert np.array_equal(u32(bmin), u32(nd["pmin"])) and np.array_equal(u32(bmax), u32(nd["pmax"]))
     assert sorted(got_positions) == sorted(pos_of[ni] for ni in leaf_nodes)  # every reference leaf exactly once
-    # triangle records: slot order = fast-tree leaf order, edges = the test's own subtractions
+    # triangle records: every slot once -- in fast-tree leaf order, or, where the scene has a wide tree, in that tree's order
+    # (check_wide) --, edges = the test's own subtractions
     tris = scene.tris()
     tri_slots = [s for k, s, _, _ in seen if k == "tri"]
-    assert tri_slots == list(range(len(tri_slots)))
+    if len(lay["wide"]):
+        assert sorted(tri_slots) == list(range(len(tri_slots)))
+    else:
+        assert tri_slots == list(range(len(tri_slots)))
     for s in (0, len(tri_slots) // 3, len(tri_slots) - 1) if tri_slots else ():
         t = tris[b1(tri_pos[s, 9])]
         assert np.array_equal(u32(tri_pos[s, 0:3]), u32(t["pos"][0]))
@@ -150,18 +154,88 @@ def check_grid(lay, flat):
     assert np.all(origin < bmin[0]) and np.all(origin + 65535.0 * step > bmax[0])
 
 
+def decode_wide(wide, origin, step):
+    """Per node: (n children, n interior, first interior child, first leaf slot, axis, lo[8,3], hi[8,3]) with the planes as
+    world coordinates, as the walk places them: origin + (org + (p << shift)) * step."""
+    out = []
+    for rec in wide:
+        planes = rec[:12].astype(np.uint32)
+        org = np.array([rec[12] & 0xFFFF, rec[12] >> 16, rec[13] & 0xFFFF], dtype=np.int64)
+        sh = np.array([(rec[13] >> 16) & 15, (rec[13] >> 20) & 15, (rec[13] >> 24) & 15], dtype=np.int64)
+        axis = int((rec[13] >> 28) & 3)
+        n_int, n_all = int((rec[15] >> 24) & 15), int(rec[15] >> 28)
+        lo = np.zeros((8, 3)); hi = np.zeros((8, 3))
+        for k in range(3):
+            for i in range(8):
+                l8 = (int(planes[4 * k + (i >> 2)]) >> (8 * (i & 3))) & 255
+                h8 = (int(planes[4 * k + 2 + (i >> 2)]) >> (8 * (i & 3))) & 255
+                lo[i, k] = float(origin[k]) + float(org[k] + (l8 << sh[k])) * float(step[k])
+                hi[i, k] = float(origin[k]) + float(org[k] + (h8 << sh[k])) * float(step[k])
+        out.append((n_all, n_int, int(rec[14]), int(rec[15] & 0xFFFFFF), axis, lo, hi))
+    return out
+
+
+def check_wide(lay):
+    """The wide form of the fast tree: every triangle slot is the leaf of exactly one node, a node's leaves are consecutive
+    slots, every node but the root is the interior child of exactly one node, the tree is at most 16 levels deep, and the
+    box of every child -- as the walk decodes it -- encloses every leaf box below it with at least a unit and a half of the
+    grid to spare."""
+    wide, rec = lay["wide"], lay["leaf_records"]
+    assert len(wide) > 0
+    step = lay["grid_step"].astype(np.float64)
+    nodes = decode_wide(wide, lay["grid_origin"].astype(np.float64), step)
+    leaf_lo = np.concatenate([rec[:, 9:11], rec[:, 12:13]], 1).astype(np.float64)
+    leaf_hi = rec[:, 13:16].astype(np.float64)
+    slot_seen = np.zeros(len(rec), dtype=np.int32)
+    node_seen = np.zeros(len(wide), dtype=np.int32)
+    node_seen[0] = 1
+
+    def visit(ni, depth):
+        """exact union of the leaf boxes below node ni"""
+        n_all, n_int, child_base, leaf_base, axis, lo, hi = nodes[ni]
+        assert 1 <= n_all <= 8 and n_int <= n_all and axis < 3 and depth <= 16
+        ulo, uhi = np.full(3, np.inf), np.full(3, -np.inf)
+        for i in range(n_all):
+            if i < n_int:
+                node_seen[child_base + i] += 1
+                clo, chi = visit(child_base + i, depth + 1)
+            else:
+                s = leaf_base + (i - n_int)
+                slot_seen[s] += 1
+                clo, chi = leaf_lo[s], leaf_hi[s]
+            assert np.all(lo[i] <= clo - 1.5 * step) and np.all(hi[i] >= chi + 1.5 * step), (ni, i)
+            ulo, uhi = np.minimum(ulo, clo), np.maximum(uhi, chi)
+        return ulo, uhi
+
+    import sys
+    sys.setrecursionlimit(10000)
+    visit(0, 0)
+    assert np.all(slot_seen == 1) and np.all(node_seen == 1)
+
+
+
 def test_grid_records_of_flat_scenes():
     for scene in (R.SdScene().load_obj(WL.DRAGON_2426).finalize(), R.SdScene().load_obj(WL.DRAGON_18520).finalize()):
-        check_grid(R.device_layout(scene), True)
+        lay = R.device_layout(scene)
+        check_grid(lay, True)
+        check_wide(lay)
     tris, _ = objparse.load_obj(WL.CYLINDER)
     # a mesh on a ground quad a hundred times its size; a scene of no thickness; a scene far from the origin
-    check_grid(R.device_layout(R.SdScene().add_model(tris).add_model(WL.ground_quad(y=-1.0, x0=-200.0, x1=200.0, z0=-200.0, z1=200.0)).finalize()), True)
+    lay = R.device_layout(R.SdScene().add_model(tris).add_model(WL.ground_quad(y=-1.0, x0=-200.0, x1=200.0, z0=-200.0, z1=200.0)).finalize())
+    check_grid(lay, True)
+    check_wide(lay)
     flat = R.device_layout(R.SdScene().add_model(WL.ground_quad()).finalize())
     check_grid(flat, True)
+    check_wide(flat)
     assert flat["grid_step"][1] * 65530.0 >= (flat["fast"][0, 3:6] - flat["fast"][0, 0:3]).max() / 8.0 * 0.999  # thin axis: an eighth of the largest extent
     far = tris.copy().reshape(-1, 3, 8)
     far[:, :, 0:3] += np.float32(300.0)
-    check_grid(R.device_layout(R.SdScene().add_model(far.reshape(-1, 24)).finalize()), True)
+    lay = R.device_layout(R.SdScene().add_model(far.reshape(-1, 24)).finalize())
+    check_grid(lay, True)
+    check_wide(lay)
+    one = R.device_layout(R.SdScene().add_model(WL.ground_quad()[:1]).finalize())   # a scene of one triangle: a root with one leaf
+    check_wide(one)
+    assert len(one["wide"]) == 1 and one["wide"][0, 15] >> 28 == 1
 
 
 def _slab_pass(lo, hi, o, inv):
