@@ -310,10 +310,16 @@ int rt_sync(rt_ctx *ctx, rt_stats *stats);
  * per plane, as six arrays of eight bytes (lo x, hi x, lo y, hi y, lo z, hi z; child i is byte i); plane value p of axis k
  * lies at grid unit org_k + (p << shift_k) of the grid above and the planes enclose the child's box with at least a unit
  * and a half to spare; word 12 org_x | org_y << 16; word 13 org_z | shift_x << 16 | shift_y << 20 | shift_z << 24 |
- * axis << 28 (the children are sorted along that axis, interior ones first, then the leaves); word 14 the index of the
+ * axis << 28 | class << 30 (the children are sorted along that axis, interior ones first, then the leaves; class = the
+ * largest leaf_class below the node); word 14 the index of the
  * first interior child (interior children are consecutive nodes); word 15 first leaf slot | interior children << 24 |
  * children << 28.  A node's leaves occupy consecutive triangle slots, and in a scene that has a wide tree the slots of
- * tri_pos / leaf_records are numbered in that tree's order instead of the fast tree's leaf order. */
+ * tri_pos / leaf_records are numbered in that tree's order instead of the fast tree's leaf order.
+ * Distance limit: with tau the smallest hit distance a ray has found so far and D the largest component of its
+ * direction (0.25 <= D <= 1.25), the walk does not enter a child of a node of class k < 3 whose box the ray meets beyond
+ * (tau + c1[k] / D + (c2 W + c3)[k]) * (1 + 2 c2[k] D) * 1.00001 -- a margin that covers, with a factor of two to spare,
+ * how far in front of its own leaf box the reference's fp32 triangle test (SimplifiedData.cpp:269-307) can report a hit
+ * on a triangle of that size class, so that no leaf that could be the reference's answer is skipped. */
 typedef struct rt_layout_view {
     uint32_t n_fast_nodes, n_ref_nodes, n_tri_slots, n_sphere_slots;
     const float *fast_nodes;
@@ -326,6 +332,9 @@ typedef struct rt_layout_view {
     float grid_origin[3], grid_step[3];
     uint32_t n_wide_nodes;       /* 0 when the scene has no wide tree */
     const uint32_t *wide_nodes;  /* 16 uint32 per node, see below */
+    uint32_t has_distance_limit; /* the wide walk skips subtrees beyond a limit derived from its closest hit so far */
+    const uint8_t *leaf_class;   /* per triangle slot: 0..2 size class of a regular leaf, 3 = never skipped */
+    float limit_constants[9];    /* by class: c1[3], 2 c2[3], (c2 W + c3)[3]; see below */
     void *owner_;
 } rt_layout_view;
 int rt_layout_scene(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt_tri *tris, uint32_t n_tris,

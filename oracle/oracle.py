@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "librt_oracle.so")
 
 TRIG_LIBM, TRIG_POLY = 0, 1
-TRAV_LOOP, TRAV_RECURSIVE, TRAV_BRUTE, TRAV_LEAVES = 0, 1, 2, 3
+TRAV_LOOP, TRAV_RECURSIVE, TRAV_BRUTE, TRAV_LEAVES, TRAV_LIMITED = 0, 1, 2, 3, 4
 ACCUM_RECURSIVE, ACCUM_FORWARD = 0, 1
 MAT_LAMBERTIAN, MAT_METAL, MAT_EMIT, MAT_DIELECTRIC = 0, 1, 2, 4
 MISS = 0xFFFFFFFF
@@ -75,6 +75,9 @@ def lib():
         L.ora_flat_node_unpack.argtypes = [fp, C.c_uint32, vp]
         L.ora_flat_tri_unpack.argtypes = [fp, C.c_uint32, vp]
         L.ora_sd_intersect.argtypes = [vp, fp, fp, C.c_int, C.POINTER(Hit)]
+        L.ora_sd_set_limit.argtypes = [vp, fp, C.POINTER(C.c_uint8), C.c_uint32]
+        L.ora_take_limit_counts.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.ora_take_limit_counts.restype = None
         L.ora_sd_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Options), C.c_int, C.c_int, C.c_int, C.c_int,
                                     fp, up, C.POINTER(Stats)]
         L.ora_old_create.restype = vp
@@ -190,6 +193,14 @@ class SdScene:
         lib().ora_sd_intersect(self.h, op, dp, traversal, C.byref(h))
         return h
 
+    def set_limit(self, constants9, class_by_triangle):
+        """Distance limit of TRAV_LIMITED: c1[3], 2 c2[3], (c2 W + c3)[3] and the size class of every triangle."""
+        c = np.ascontiguousarray(constants9, dtype=np.float32).reshape(9)
+        k = np.ascontiguousarray(class_by_triangle, dtype=np.uint8)
+        rc = lib().ora_sd_set_limit(self.h, c.ctypes.data_as(C.POINTER(C.c_float)), k.ctypes.data_as(C.POINTER(C.c_uint8)), len(k))
+        if rc != 0:
+            raise ValueError("one class per triangle of the scene is needed")
+
     def render(self, cam, opt, width, height, first_sample=1, n_samples=1, image=None, want_primary=False):
         return _render(lib().ora_sd_render, self.h, cam, opt, width, height, first_sample, n_samples, image,
                        want_primary)
@@ -292,6 +303,13 @@ def vec_op(op, a, b=None, c=None, v=None):
     keep = [_f(x) if x is not None else (None, None) for x in (a, b, c, v)]
     lib().ora_vec_op(op, keep[0][1], keep[1][1], keep[2][1], keep[3][1], out.ctypes.data_as(C.POINTER(C.c_float)))
     return out[0] if op == VEC_DOT else out
+
+
+def take_limit_counts():
+    """(leaves TRAV_LIMITED skipped, leaves whose box a ray met) since the last call."""
+    a, b = C.c_uint64(), C.c_uint64()
+    lib().ora_take_limit_counts(C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
 
 
 def take_leaf_replays():

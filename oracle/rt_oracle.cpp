@@ -212,6 +212,7 @@ inline V3 tri_normal(V3 n0, V3 n1, V3 n2, float u, float v) {
 }
 
 static std::atomic<uint64_t> g_leaf_replays{0}; // rays ORA_TRAV_LEAVES resolved by the ordered replay
+static std::atomic<uint64_t> g_leaves_skipped{0}, g_leaves_met{0}; // ORA_TRAV_LIMITED: leaves beyond the limit / leaves whose box the ray meets
 
 // =================================================================== flat-array ("sd") scene
 enum : uint32_t { NODE_INTERNAL = 0, NODE_LEAF = 1 }; // SimplifiedData.hpp:30-36
@@ -456,6 +457,80 @@ struct SdScene {
         return h;
     }
 
+    // ---- the same with a DISTANCE LIMIT (checks the argument the product's wide walk rests on) ----
+    // A walk that already knows a hit at distance tau may skip a leaf whose box the ray enters at m, if no ray for which
+    // the triangle test reports a hit can have m - t as large as that: then a skipped leaf cannot be a candidate with
+    // t <= tau, and only such candidates can change the outcome (the candidate with the smallest (t, pos) is still found,
+    // and so is every candidate below it that could force the replay).  The margin is the caller's: per size class k of the
+    // leaf, skip when m >= (tau + c1[k] / D + c3[k]) * (1 + c2x2[k] * D) * 1.00001, D = |d|_inf in [0.25, 1.25]; class 3 is
+    // never skipped.  The leaves are visited NEAREST BOX FIRST, the order in which the limit cuts most.
+    std::vector<uint8_t> limitClass; // per triangle
+    float limitC1[3] = {0, 0, 0}, limitC2x2[3] = {0, 0, 0}, limitC3[3] = {0, 0, 0};
+    SdHit intersectLimited(const Ray &ray, Counters &c, bool *replayed) const {
+        struct Boxed {
+            float m;
+            uint32_t node;
+        };
+        std::vector<Boxed> met;
+        for (uint32_t index = 0; index < (uint32_t)nodes.size(); index++) {
+            const SdNode &node = nodes[index];
+            if (node.flags != NODE_LEAF || leafPos[index] == 0xFFFFFFFFu)
+                continue;
+            c.box++;
+            float m;
+            if (box_entry(node.pmin, node.pmax, ray, &m))
+                met.push_back(Boxed{m, index});
+        }
+        std::sort(met.begin(), met.end(), [](const Boxed &a, const Boxed &b) { return a.m < b.m || (a.m == b.m && a.node < b.node); });
+        const float D = std::max(std::fabs(ray.d.x), std::max(std::fabs(ray.d.y), std::fabs(ray.d.z)));
+        const bool limited = !limitClass.empty() && D >= 0.25f && D <= 1.25f;
+        const float invD = limited ? 1.0f / D : 1.0f;
+        float tau = kInf;
+        bool have = false;
+        float bt = kInf, bmm = 0.0f;
+        uint32_t bpos = 0xFFFFFFFFu, bnode = 0;
+        uint64_t skipped = 0;
+        for (const Boxed &b : met) {
+            const SdNode &node = nodes[b.node];
+            const uint32_t cls = limited ? limitClass[node.left] : 3u;
+            if (cls < 3u) {
+                const float limit = (tau + std::fma(limitC1[cls], invD, limitC3[cls])) * std::fma(limitC2x2[cls], D, 1.00001f);
+                if (b.m >= limit) {
+                    skipped++;
+                    continue;
+                }
+            }
+            const SdTri &tri = tris[node.left];
+            c.tri++;
+            TriHit th = tri_test(tri.p[0], tri.p[1], tri.p[2], ray);
+            if (!th.hit || !(th.t < kInf))
+                continue;
+            const uint32_t pos = leafPos[b.node];
+            if (!have || th.t < bt || (th.t == bt && pos < bpos)) {
+                have = true;
+                bt = th.t;
+                bpos = pos;
+                bmm = b.m;
+                bnode = b.node;
+            }
+            tau = th.t < tau ? th.t : tau;
+        }
+        g_leaves_skipped += skipped;
+        g_leaves_met += met.size();
+        *replayed = false;
+        SdHit h;
+        if (!have)
+            return h;
+        if (bmm > bt) { // the winner lies in front of its own leaf box: nothing may be skipped, play the rule over all leaves
+            Counters scratch;
+            h = intersectLeaves(ray, scratch, replayed);
+            *replayed = true;
+            return h;
+        }
+        Counters scratch;
+        return leafHit(nodes[bnode], ray, scratch);
+    }
+
     // brute force over all triangles in storage order (the "BVH acceleration off" debugging aid)
     SdHit intersectBrute(const Ray &ray, Counters &c) const {
         SdHit closest;
@@ -475,9 +550,9 @@ struct SdScene {
             intersectRec(root, ray, h, c);
         else if (trav == ORA_TRAV_BRUTE)
             h = intersectBrute(ray, c);
-        else if (trav == ORA_TRAV_LEAVES) {
+        else if (trav == ORA_TRAV_LEAVES || trav == ORA_TRAV_LIMITED) {
             bool replayed = false;
-            h = intersectLeaves(ray, c, &replayed);
+            h = trav == ORA_TRAV_LEAVES ? intersectLeaves(ray, c, &replayed) : intersectLimited(ray, c, &replayed);
             if (replayed)
                 g_leaf_replays++;
         } else
@@ -915,6 +990,22 @@ int ora_sd_finalize(void *s) {
 }
 
 uint64_t ora_take_leaf_replays(void) { return g_leaf_replays.exchange(0); }
+void ora_take_limit_counts(uint64_t *skipped, uint64_t *met) {
+    *skipped = g_leaves_skipped.exchange(0);
+    *met = g_leaves_met.exchange(0);
+}
+int ora_sd_set_limit(void *s, const float *c9, const uint8_t *class_by_triangle, uint32_t n_triangles) {
+    SdScene &sc = *(SdScene *)s;
+    if (n_triangles != sc.tris.size())
+        return -1;
+    sc.limitClass.assign(class_by_triangle, class_by_triangle + n_triangles);
+    for (int k = 0; k < 3; k++) {
+        sc.limitC1[k] = c9[k];
+        sc.limitC2x2[k] = c9[3 + k];
+        sc.limitC3[k] = c9[6 + k];
+    }
+    return 0;
+}
 void ora_sd_counts(void *s, uint32_t *n_nodes, uint32_t *n_tris, uint32_t *root) {
     SdScene &sc = *(SdScene *)s;
     *n_nodes = (uint32_t)sc.nodes.size();

@@ -34,8 +34,10 @@ typedef struct ora_camera {
 
 enum { ORA_TRIG_LIBM = 0, ORA_TRIG_POLY = 1 };
 enum { ORA_TRAV_LOOP = 0, ORA_TRAV_RECURSIVE = 1, ORA_TRAV_BRUTE = 2,
-       ORA_TRAV_LEAVES = 3 /* flat scene only: IntersectLoop's result derived from the leaves alone, visited in an
-                              unrelated order (the argument the product's fast walk rests on) */ };
+       ORA_TRAV_LEAVES = 3, /* flat scene only: IntersectLoop's result derived from the leaves alone, visited in an
+                              unrelated order (the argument the product's fast walk rests on) */
+       ORA_TRAV_LIMITED = 4 /* ... the same, nearest leaf box first, skipping the leaves beyond a distance limit derived from
+                              the closest hit so far (ora_sd_set_limit; the argument the product's wide walk rests on) */ };
 enum { ORA_ACCUM_RECURSIVE = 0, ORA_ACCUM_FORWARD = 1 };
 
 typedef struct ora_options {
@@ -95,6 +97,12 @@ void ora_flat_tri_unpack(const float *flat25, uint32_t index, void *out100);
 void ora_sd_intersect(void *scene, const float *origin, const float *dir, int traversal, ora_hit *out);
 /* Rays ORA_TRAV_LEAVES had to resolve by the ordered replay since the last call of this function. */
 uint64_t ora_take_leaf_replays(void);
+/* The distance limit of ORA_TRAV_LIMITED: c9 = c1[3], 2 c2[3], (c2 W + c3)[3] by size class, and the class of every
+ * triangle (0..2, 3 = never skipped).  A leaf of class k < 3 is skipped when the ray enters its box at or beyond
+ * (tau + c1[k] / D + c3[k]) * (1 + 2 c2[k] D) * 1.00001, tau the closest hit so far, D = |d|_inf in [0.25, 1.25]. */
+int ora_sd_set_limit(void *scene, const float *c9, const uint8_t *class_by_triangle, uint32_t n_triangles);
+/* Leaves ORA_TRAV_LIMITED skipped / leaves whose box a ray met, since the last call. */
+void ora_take_limit_counts(uint64_t *skipped, uint64_t *met);
 /* Renders samples first_sample .. first_sample+n_samples-1 (1-based sampleCount of
  * Renderer/TracerImpl.cpp:11) as a running mean into image (W*H*4 floats, row 0 = bottom). */
 int ora_sd_render(void *scene, const ora_camera *cam, const ora_options *opt, int width, int height,

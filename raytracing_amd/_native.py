@@ -55,6 +55,7 @@ class LayoutViewC(C.Structure):  # rt_layout_view
                 ("tri_pos", C.POINTER(C.c_float)), ("spheres", C.POINTER(C.c_float)), ("n_grid_nodes", C.c_uint32),
                 ("grid_nodes", C.POINTER(C.c_uint32)), ("leaf_records", C.POINTER(C.c_float)), ("grid_origin", C.c_float * 3),
                 ("grid_step", C.c_float * 3), ("n_wide_nodes", C.c_uint32), ("wide_nodes", C.POINTER(C.c_uint32)),
+                ("has_distance_limit", C.c_uint32), ("leaf_class", C.POINTER(C.c_uint8)), ("limit_constants", C.c_float * 9),
                 ("owner_", C.c_void_p)]
 
 

@@ -54,7 +54,7 @@ struct KParams {
     const uint4 *wnodes;       // wide fast tree (flat scenes): 64 bytes per node of up to eight children, see build_wide
     uint32_t wide_depth;       // ... and the entries a lane's stack needs for it (interior levels below the root, at least 1)
     int prune;                 // the wide walk keeps a distance limit (the scene's leaves allow one, see LeafShape in scene_layout.hpp)
-    float prune_c1, prune_c2, prune_c3; // ... its constants: c1, c2, c2 W + c3
+    float prune_c1[3], prune_c2x2[3], prune_c3[3]; // ... its constants by leaf class: c1, 2 c2, c2 W + c3
     f3 q_origin, q_step;       // ... and the grid its 16-bit planes live on
     int compact;               // the sliced / re-fill walks go over the compact tree (2: two records per trip to memory; 3: the re-fill walk goes over the wide tree)
     uint32_t slice_quorum;     // k_sliced: a wave with no more walking lanes than this ends its slice

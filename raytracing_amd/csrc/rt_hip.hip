@@ -105,7 +105,7 @@ struct rt_ctx {
     bool has_wide = false;
     uint32_t n_wide = 0, wide_depth = 1;
     bool can_prune = false;
-    float prune_c[3] = {0.f, 0.f, 0.f};
+    float prune_c[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; // c1[3], 2 c2[3], c2 W + c3 [3]
     float q_origin[3] = {0, 0, 0}, q_step[3] = {1, 1, 1};
     bool has_compact = false;
     double compact_inflation = 1.0;
@@ -519,9 +519,11 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     P.wnodes = (const uint4 *)ctx->d_wnodes;
     P.wide_depth = ctx->wide_depth;
     P.prune = ctx->can_prune && tuning().prune != 0 ? 1 : 0;
-    P.prune_c1 = ctx->prune_c[0];
-    P.prune_c2 = ctx->prune_c[1];
-    P.prune_c3 = ctx->prune_c[2];
+    for (int k = 0; k < 3; k++) {
+        P.prune_c1[k] = ctx->prune_c[k];
+        P.prune_c2x2[k] = ctx->prune_c[3 + k];
+        P.prune_c3[k] = ctx->prune_c[6 + k];
+    }
     P.leaf_boxes = ctx->d_leaf_boxes;
     P.q_origin = mk3(ctx->q_origin[0], ctx->q_origin[1], ctx->q_origin[2]);
     P.q_step = mk3(ctx->q_step[0], ctx->q_step[1], ctx->q_step[2]);
@@ -1056,10 +1058,12 @@ int upload_layout(rt_ctx *ctx, const SceneLayout &L) {
             ctx->has_wide = true;
             ctx->n_wide = L.n_wide;
             ctx->wide_depth = L.wide_depth > 0 ? L.wide_depth : 1u;
-            ctx->can_prune = L.prune_c1 > 0.f;
-            ctx->prune_c[0] = L.prune_c1;
-            ctx->prune_c[1] = L.prune_c2;
-            ctx->prune_c[2] = L.prune_c3;
+            ctx->can_prune = L.prune;
+            for (int k = 0; k < 3; k++) {
+                ctx->prune_c[k] = L.prune_c1[k];
+                ctx->prune_c[3 + k] = L.prune_c2x2[k];
+                ctx->prune_c[6 + k] = L.prune_c3[k];
+            }
         }
         ctx->has_compact = true;
         ctx->compact_inflation = L.compact_inflation;
@@ -1068,7 +1072,9 @@ int upload_layout(rt_ctx *ctx, const SceneLayout &L) {
             std::fprintf(stderr, "compact inflation %.4f expected visits %.2f fast visits %.2f scene bytes %zu; wide %d: %u nodes, depth %u, visits %.2f\n",
                          L.compact_inflation, L.expected_visits, L.fast_visits, (L.fn.size() + L.tp.size()) * sizeof(float4), (int)L.wide, L.n_wide,
                          L.wide_depth, L.wide_visits);
-            std::fprintf(stderr, "distance limit: c1 %.3g c2 %.3g c2W+c3 %.3g, %u irregular leaves\n", L.prune_c1, L.prune_c2, L.prune_c3, L.n_irregular);
+            std::fprintf(stderr, "distance limit %d: c1 %.3g %.3g %.3g  2 c2 %.3g %.3g %.3g  c2W+c3 %.3g %.3g %.3g, %u irregular leaves\n", (int)L.prune,
+                         L.prune_c1[0], L.prune_c1[1], L.prune_c1[2], L.prune_c2x2[0], L.prune_c2x2[1], L.prune_c2x2[2], L.prune_c3[0], L.prune_c3[1],
+                         L.prune_c3[2], L.n_irregular);
         }
     }
     ctx->expected_visits = L.expected_visits;
@@ -1788,6 +1794,13 @@ int rt_layout_scene(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const
     if (L->wide) {
         out->n_wide_nodes = L->n_wide;
         out->wide_nodes = reinterpret_cast<const uint32_t *>(L->wn.data());
+        out->has_distance_limit = L->prune ? 1u : 0u;
+        out->leaf_class = L->leaf_class.data();
+        for (int k = 0; k < 3; k++) {
+            out->limit_constants[k] = L->prune_c1[k];
+            out->limit_constants[3 + k] = L->prune_c2x2[k];
+            out->limit_constants[6 + k] = L->prune_c3[k];
+        }
     }
     out->owner_ = L;
     return RT_OK;

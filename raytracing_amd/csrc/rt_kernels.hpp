@@ -607,20 +607,18 @@ __global__ void __launch_bounds__(256, COMPACT == 3 ? RT_WIDE_WAVES : 1) k_refil
     uint32_t bpos = kNone;
     float bm = 0.0f;
     GridRay grid = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
-    // wide walk: the ray's distance limit is (smallest hit distance so far) * lim_a + lim_b, +inf while lim_a is +inf
-    float lim_a = __builtin_inff(), lim_b = 0.0f;
+    // wide walk: the largest component of the ray's direction and its reciprocal, for the distance limit; `limited`: the
+    // ray takes one (the scene offers a limit and the component is within the range its margin was derived for)
+    float dmax = 1.0f, inv_dmax = 1.0f;
+    bool limited = false;
     auto start_walk = [&]() {
         path.inv = mk3(1.0f / path.d.x, 1.0f / path.d.y, 1.0f / path.d.z); // Ray::Ray, CPURayTrace/Ray.hpp:8
         if (COMPACT)
             grid = grid_ray(P, path.o, path.inv);
         if (WIDE) {
-            const float dmax = fmaxf(fmaxf(__builtin_fabsf(path.d.x), __builtin_fabsf(path.d.y)), __builtin_fabsf(path.d.z));
-            lim_a = __builtin_inff();
-            lim_b = 0.0f;
-            if (P.prune != 0 && dmax >= 0.25f && dmax <= 1.25f) {
-                lim_a = (1.0f + 2.0f * P.prune_c2 * dmax) * 1.00001f;
-                lim_b = (P.prune_c1 / dmax + P.prune_c3) * lim_a;
-            }
+            dmax = fmaxf(fmaxf(__builtin_fabsf(path.d.x), __builtin_fabsf(path.d.y)), __builtin_fabsf(path.d.z));
+            limited = P.prune != 0 && dmax >= 0.25f && dmax <= 1.25f;
+            inv_dmax = limited ? 1.0f / dmax : 1.0f;
         }
         w = Walk{0u, kNone, kNone, 0.0f};
         sp = 0u;
@@ -630,11 +628,10 @@ __global__ void __launch_bounds__(256, COMPACT == 3 ? RT_WIDE_WAVES : 1) k_refil
         J.key[lane] = ~0ull;
         cnt.rays++;
     };
-    // The distance limit of this lane's walk, from the closest hit it knows of: its own tests and what the noted tests that
-    // have run so far left in the wave's list (the key's upper word is the hit distance, all ones -- not a number -- for none).
-    auto walk_limit = [&]() -> float {
-        const float tau = fminf(best.t, __uint_as_float((uint32_t)(J.key[lane] >> 32)));
-        return lim_a < __builtin_inff() ? __builtin_fmaf(tau, lim_a, lim_b) : __builtin_inff();
+    // The closest hit this lane's walk knows of, for its distance limit: its own tests and what the noted tests that have run
+    // so far left in the wave's list (the key's upper word is the hit distance, all ones -- not a number -- for none).
+    auto closest_so_far = [&]() -> float {
+        return limited ? fminf(best.t, __uint_as_float((uint32_t)(J.key[lane] >> 32))) : __builtin_inff();
     };
     for (;;) {
         // ---- free lanes take the next items of the held batch; a used-up batch is replaced from the group's cursor ----
@@ -706,7 +703,7 @@ __global__ void __launch_bounds__(256, COMPACT == 3 ? RT_WIDE_WAVES : 1) k_refil
         for (;;) {
             if constexpr (WIDE) {
                 if (has && w.idx < n)
-                    wide_walk_from<STATS>(P, grid, w.idx, sp, stk, kWideBurst, walk_limit(), cnt,
+                    wide_walk_from<STATS>(P, grid, w.idx, sp, stk, kWideBurst, closest_so_far(), dmax, inv_dmax, cnt,
                                       [&](const uint32_t k) { return atomicAdd(&J.count, k); },
                                       [&](const uint32_t j, const uint32_t slot) { note_leaf<STATS>(P, lane, j, slot, path, J, best, bpos, bm, cnt); });
             } else if constexpr (COMPACT != 0) {
@@ -735,7 +732,7 @@ __global__ void __launch_bounds__(256, COMPACT == 3 ? RT_WIDE_WAVES : 1) k_refil
             // soon as there is a full pass of them: what they find shortens the walks that go on
             if (J.count + JobList::kCap / 2u > JobList::kCap || (WIDE && P.prune != 0 && J.count >= 64u)) {
                 if constexpr (COMPACT != 0)
-                    resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt, WIDE ? walk_limit() : __builtin_inff());
+                    resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt);
                 else
                     resolve_jobs<OLD>(P, lane, path.o, path.d, J);
             }
@@ -749,7 +746,7 @@ __global__ void __launch_bounds__(256, COMPACT == 3 ? RT_WIDE_WAVES : 1) k_refil
         }
         // ---- shade the finished walks ----
         if constexpr (COMPACT != 0)
-            resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt, WIDE ? walk_limit() : __builtin_inff());
+            resolve_jobs_compact<STATS>(P, lane, path.o, path.d, path.inv, J, cnt);
         else
             resolve_jobs<OLD>(P, lane, path.o, path.d, J);
         take_noted_result(has && !(w.idx < n), lane, J, best, bpos, bm);

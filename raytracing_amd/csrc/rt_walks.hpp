@@ -865,11 +865,13 @@ constexpr uint32_t kWideDone = 0xFFFFFFFFu; // value of the walk's position once
 RT_D float ubyte_f(const uint32_t w, const int i) { return (float)((w >> (8 * i)) & 0xFFu); }
 
 // Takes the walk at most `steps` nodes further.  cur: node the lane stands on (kWideDone: the walk is over); sp: entries
-// on the lane's stack.  `limit`: the walk does not enter a box the ray meets at or beyond that distance (+inf: no limit).
+// on the lane's stack.  `tau`: the smallest hit distance the ray knows of, +inf for none or for a ray that takes no
+// distance limit; dmax, inv_dmax: the largest component of the ray's direction and its reciprocal.  The walk does not enter
+// a child whose box the ray meets at or beyond the limit of the node's class (see LeafShape in scene_layout.hpp).
 // `reserve(n)` hands out n consecutive places in the wave's list of noted tests, `commit(place, slot)` notes one.
 template <bool STATS, class R, class C>
-RT_D void wide_walk_from(const KParams &P, const GridRay g, uint32_t &cur, uint32_t &sp, uint32_t *stk, int steps, const float limit,
-                         Cnt &cnt, R &&reserve, C &&commit) {
+RT_D void wide_walk_from(const KParams &P, const GridRay g, uint32_t &cur, uint32_t &sp, uint32_t *stk, int steps, const float tau,
+                         const float dmax, const float inv_dmax, Cnt &cnt, R &&reserve, C &&commit) {
     uint32_t at = cur, top = sp;
     // A leaf the ray meets is noted in two halves, as in compact_walk_from: the places in the wave's list are asked for (an
     // LDS atomic whose answer takes a hundred cycles) as soon as the node's tests are done, the jobs are written once the
@@ -908,7 +910,12 @@ RT_D void wide_walk_from(const KParams &P, const GridRay g, uint32_t &cur, uint3
         const uint32_t nx0 = dnx ? r0.z : r0.x, nx1 = dnx ? r0.w : r0.y, fx0 = dnx ? r0.x : r0.z, fx1 = dnx ? r0.y : r0.w;
         const uint32_t ny0 = dny ? r1.z : r1.x, ny1 = dny ? r1.w : r1.y, fy0 = dny ? r1.x : r1.z, fy1 = dny ? r1.y : r1.w;
         const uint32_t nz0 = dnz ? r2.z : r2.x, nz1 = dnz ? r2.w : r2.y, fz0 = dnz ? r2.x : r2.z, fz1 = dnz ? r2.y : r2.w;
-        const float here = (r3.y & (1u << 30)) != 0u ? __builtin_inff() : limit; // nodes above a leaf the limit's bound does not cover
+        // the distance limit of this node's class: (tau + c1 / D + c2 W + c3) * (1 + 2 c2 D) * 1.00001; none for class 3
+        const uint32_t cls = r3.y >> 30;
+        const float k1 = cls == 0u ? P.prune_c1[0] : cls == 1u ? P.prune_c1[1] : P.prune_c1[2];
+        const float k2 = cls == 0u ? P.prune_c2x2[0] : cls == 1u ? P.prune_c2x2[1] : P.prune_c2x2[2];
+        const float k3 = cls == 0u ? P.prune_c3[0] : cls == 1u ? P.prune_c3[1] : P.prune_c3[2];
+        const float here = cls == 3u ? __builtin_inff() : (tau + __builtin_fmaf(k1, inv_dmax, k3)) * __builtin_fmaf(k2, dmax, 1.00001f);
         uint32_t hits = 0u;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -956,11 +963,8 @@ RT_D void wide_walk_from(const KParams &P, const GridRay g, uint32_t &cur, uint3
 
 // resolve_jobs for the compact walk: a job is a leaf whose grid box the owner's ray met; it runs the leaf's exact box test
 // and, if that passes, the triangle test.  `o`, `d`, `inv`: this lane's own ray.
-// `limit`: this lane's distance limit (wide walk; +inf elsewhere): a job whose leaf box the owner's ray enters beyond the
-// owner's limit is dropped untested.
 template <bool STATS, class JT>
-RT_D void resolve_jobs_compact(const KParams &P, const uint32_t lane, const f3 o, const f3 d, const f3 inv, JT &J, Cnt &cnt,
-                               const float limit = __builtin_inff()) {
+RT_D void resolve_jobs_compact(const KParams &P, const uint32_t lane, const f3 o, const f3 d, const f3 inv, JT &J, Cnt &cnt) {
     const float inf = __builtin_inff();
     __builtin_amdgcn_wave_barrier();
     const uint32_t noted = J.count;
@@ -980,7 +984,6 @@ RT_D void resolve_jobs_compact(const KParams &P, const uint32_t lane, const f3 o
         const f3 ri = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.x))),
                           __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.y))),
                           __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.z))));
-        const float rlimit = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(limit)));
         bool hit = false;
         unsigned long long key = ~0ull;
         float hu = 0.0f, hv = 0.0f, ht = 0.0f, hm = 0.0f;
@@ -989,7 +992,7 @@ RT_D void resolve_jobs_compact(const KParams &P, const uint32_t lane, const f3 o
             const float4 q0 = P.leaf_boxes[4 * slot], q1 = P.leaf_boxes[4 * slot + 1], q2 = P.leaf_boxes[4 * slot + 2], q3 = P.leaf_boxes[4 * slot + 3];
             if (STATS)
                 cnt.box++;
-            if (exact_leaf_entry(q2, q3, ro, ri, hm) && !(hm > rlimit)) {
+            if (exact_leaf_entry(q2, q3, ro, ri, hm)) {
                 if (STATS)
                     cnt.tri++;
                 float t, u, v;

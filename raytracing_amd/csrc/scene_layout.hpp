@@ -22,8 +22,12 @@ struct SceneLayout {
     uint32_t n_wide = 0, wide_depth = 0;
     bool wide = false;
     double wide_visits = 0.0; // surface area of all wide nodes' boxes / the root's
-    // Distance limit of the wide walk (see prune_constants): 0 in prune_c2 = the scene offers none.
-    float prune_c1 = 0.f, prune_c2 = 0.f, prune_c3 = 0.f;
+    // Distance limit of the wide walk (see LeafShape): constants c1, 2 c2, c2 W + c3 of the three classes of regular leaves
+    // (each class includes the ones below it), the class of every triangle slot (3: not regular, never skipped), and whether
+    // the scene offers a limit at all.
+    float prune_c1[3] = {0.f, 0.f, 0.f}, prune_c2x2[3] = {0.f, 0.f, 0.f}, prune_c3[3] = {0.f, 0.f, 0.f};
+    std::vector<uint8_t> leaf_class;
+    bool prune = false;
     uint32_t n_irregular = 0;
 };
 
@@ -48,7 +52,11 @@ struct SceneLayout {
 // 1 / (1 - x) <= 1 + 2 x for x <= 1/2:  a subtree is skipped when  e > (tau * A + B) * (1 + 1e-5),  A = 1 + 2 c2 D,
 // B = (c1 / D + c2 W + c3) * A,  for rays with 0.25 <= D <= 1.25.  A leaf is regular when its numbers are finite,
 // a b <= 1e-3 (so c2 D <= 0.425), p0 + e1 and p0 + e2 lie inside its box, and its size is not far above the scene's
-// typical leaf (a ground quad under a mesh is not regular); nodes above an irregular leaf are never skipped.
+// typical leaf (a ground quad under a mesh is not regular).  Because the constants grow with the leaves' size, regular
+// leaves come in three classes by size -- up to twice the median width (four times the median a b), up to twice the
+// 90th percentile, up to four times the 99th (sixteen times for a b) -- each with the maxima over its own and the smaller
+// classes; a node of the wide tree carries the largest class among the leaves below it and its children are skipped by
+// that class's limit; class 3 (an irregular leaf below) is never skipped.
 struct LeafShape {
     float a, b, w; // |e1|_inf, |e2|_inf, largest extent of the leaf box
     bool sane;     // finite, a b <= 1e-3, the triangle as stored lies inside its box
@@ -84,8 +92,8 @@ inline LeafShape leaf_shape(const rt_tri &t, const rt_node &leaf) {
 //                 uses (SceneLayout::q_origin / q_step), and the planes enclose the child's box with TWO grid units to
 //                 spare (the compact tree's one, and one more for the second rounding of the two-step evaluation);
 //   dword 12      org_x | org_y << 16
-//   dword 13      org_z | shift_x << 16 | shift_y << 20 | shift_z << 24 | axis << 28 | (no distance limit here) << 30:
-//                 the flag marks the nodes above a leaf the limit's error bound does not cover (prune_constants)
+//   dword 13      org_z | shift_x << 16 | shift_y << 20 | shift_z << 24 | axis << 28 | class << 30: the largest class, under
+//                 the distance limit, of the leaves below the node (LeafShape; 3 = no limit at this node)
 //   dword 14      index of the node's first interior child; interior children are consecutive records
 //   dword 15      first leaf slot (24 bits) | interior children << 24 (4 bits) | children << 28 (4 bits)
 // Children are ordered along `axis` (the axis over which their centres spread most), interior ones first, leaves after
@@ -105,8 +113,8 @@ struct WideBuild {
 };
 
 // bn: the binary fast tree in pre-order (fastbvh::Node); q_origin / q_step: the grid.
-// irregular: per binary node, non-zero for a leaf whose triangle the distance limit's bound does not cover (may be empty).
-inline void build_wide(const std::vector<fastbvh::Node> &bn, const float *q_origin, const float *q_step, const std::vector<uint8_t> &irregular,
+// leaf_class: per binary node, for a leaf the class of its triangle under the distance limit (0..2, 3 = never skipped); may be empty.
+inline void build_wide(const std::vector<fastbvh::Node> &bn, const float *q_origin, const float *q_step, const std::vector<uint8_t> &leaf_class,
                        WideBuild &W) {
     const uint32_t nb = (uint32_t)bn.size();
     W.ok = false;
@@ -114,14 +122,14 @@ inline void build_wide(const std::vector<fastbvh::Node> &bn, const float *q_orig
     W.wn.clear();
     if (nb == 0)
         return;
-    // binary subtrees that hold an irregular leaf (children follow their parent in the array: one pass from the back)
+    // the largest leaf class in every binary subtree (children follow their parent in the array: one pass from the back)
     std::vector<uint8_t> tainted(nb, 0);
-    if (!irregular.empty())
+    if (!leaf_class.empty())
         for (uint32_t q = nb; q-- > 0;) {
             if (bn[q].item != 0xFFFFFFFFu)
-                tainted[q] = irregular[q];
+                tainted[q] = leaf_class[q];
             else
-                tainted[q] = tainted[q + 1u] | tainted[q + 1u + bn[q + 1u].size];
+                tainted[q] = std::max(tainted[q + 1u], tainted[q + 1u + bn[q + 1u].size]);
         }
     auto half_area = [&](uint32_t c) {
         const double x = (double)bn[c].bmax[0] - bn[c].bmin[0], y = (double)bn[c].bmax[1] - bn[c].bmin[1], z = (double)bn[c].bmax[2] - bn[c].bmin[2];
@@ -242,7 +250,7 @@ inline void build_wide(const std::vector<fastbvh::Node> &bn, const float *q_orig
         rec[2] = make_uint4(planes[8], planes[9], planes[10], planes[11]);
         rec[3] = make_uint4((uint32_t)org[0] | ((uint32_t)org[1] << 16),
                             (uint32_t)org[2] | ((uint32_t)sh[0] << 16) | ((uint32_t)sh[1] << 20) | ((uint32_t)sh[2] << 24) | ((uint32_t)axis << 28) |
-                                (tainted[t.q] ? 1u << 30 : 0u),
+                                ((uint32_t)tainted[t.q] << 30),
                             child_base, leaf_base | ((uint32_t)ni << 24) | ((uint32_t)n << 28));
         for (int i = ni; i-- > 0;) // first child on top: nodes are made in depth-first order
             todo.push_back(Todo{ch[i], child_base + (uint32_t)i, t.depth + 1u});
@@ -410,7 +418,7 @@ int build_layout(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt
         if (grid_ok) {
             // the leaves' shapes: which are regular, and the distance limit's constants over those (see above LeafShape)
             const uint32_t nbn = (uint32_t)top_nodes.size();
-            std::vector<uint8_t> irregular(nbn, 0);
+            std::vector<uint8_t> irregular(nbn, 0); // per binary node: a leaf's class (3 = irregular)
             std::vector<LeafShape> shape(nbn);
             std::vector<float> widths, products;
             for (uint32_t q = 0; q < nbn; q++)
@@ -422,38 +430,58 @@ int build_layout(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt
                         products.push_back(shape[q].a * shape[q].b);
                     }
                 }
-            float w_cap = 0.f, ab_cap = 0.f;
-            if (!widths.empty()) { // "not far above the typical leaf": four times the 99th percentile of the widths, sixteen of the products
-                const size_t k = (widths.size() - 1) * 99 / 100;
-                std::nth_element(widths.begin(), widths.begin() + k, widths.end());
-                std::nth_element(products.begin(), products.begin() + k, products.end());
-                w_cap = 4.f * widths[k];
-                ab_cap = 16.f * products[k];
+            float w_cap[3] = {0.f, 0.f, 0.f}, ab_cap[3] = {0.f, 0.f, 0.f};
+            if (!widths.empty()) {
+                const size_t n = widths.size(), at[3] = {(n - 1) / 2, (n - 1) * 90 / 100, (n - 1) * 99 / 100};
+                const float wf[3] = {2.f, 2.f, 4.f}, pf[3] = {4.f, 4.f, 16.f};
+                for (int k = 0; k < 3; k++) {
+                    std::nth_element(widths.begin(), widths.begin() + at[k], widths.end());
+                    std::nth_element(products.begin(), products.begin() + at[k], products.end());
+                    w_cap[k] = wf[k] * widths[at[k]];
+                    ab_cap[k] = pf[k] * products[at[k]];
+                    if (k > 0) { // (the caps never shrink from one class to the next)
+                        w_cap[k] = std::max(w_cap[k], w_cap[k - 1]);
+                        ab_cap[k] = std::max(ab_cap[k], ab_cap[k - 1]);
+                    }
+                }
             }
-            double c1 = 0.0, c2 = 0.0, c3 = 0.0, wmax = 0.0;
+            double c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0}, c3[3] = {0, 0, 0}, wmax[3] = {0, 0, 0};
             uint32_t n_irr = 0, n_leaf = 0;
             for (uint32_t q = 0; q < nbn; q++)
                 if (top_nodes[q].item != 0xFFFFFFFFu) {
                     const LeafShape &sh = shape[q];
                     n_leaf++;
-                    if (!sh.sane || sh.w > w_cap || sh.a * sh.b > ab_cap) {
-                        irregular[q] = 1;
+                    int cls = 3;
+                    for (int k = 2; k >= 0; k--)
+                        if (sh.sane && sh.w <= w_cap[k] && sh.a * sh.b <= ab_cap[k])
+                            cls = k;
+                    irregular[q] = (uint8_t)cls;
+                    if (cls == 3) {
                         n_irr++;
                         continue;
                     }
                     const double a = sh.a, b = sh.b;
-                    c1 = std::max(c1, 2.0 * ((double)sh.w + 3e-7 * (a + b)));
-                    c2 = std::max(c2, 340.0 * a * b);
-                    c3 = std::max(c3, 146.0 * a * b * (a + b));
-                    wmax = std::max(wmax, (double)sh.w);
+                    for (int k = cls; k < 3; k++) {
+                        c1[k] = std::max(c1[k], 2.0 * ((double)sh.w + 3e-7 * (a + b)));
+                        c2[k] = std::max(c2[k], 340.0 * a * b);
+                        c3[k] = std::max(c3[k], 146.0 * a * b * (a + b));
+                        wmax[k] = std::max(wmax[k], (double)sh.w);
+                    }
                 }
             L.n_irregular = n_irr;
-            if (n_leaf > 0 && (double)n_irr <= 0.02 * (double)n_leaf + 16.0 && c2 * 1.25 <= 0.5) {
-                L.prune_c1 = (float)(c1 * 1.000001);
-                L.prune_c2 = (float)(c2 * 1.000001);
-                L.prune_c3 = (float)((c2 * wmax + c3) * 1.000001); // c2 W + c3
+            L.prune = n_leaf > 0 && (double)n_irr <= 0.02 * (double)n_leaf + 16.0 && c2[2] * 1.25 <= 0.5;
+            for (int k = 0; k < 3; k++) {
+                L.prune_c1[k] = (float)(c1[k] * 1.000001);
+                L.prune_c2x2[k] = (float)(2.0 * c2[k] * 1.000001);
+                L.prune_c3[k] = (float)((c2[k] * wmax[k] + c3[k]) * 1.000001); // c2 W + c3
             }
             build_wide(top_nodes, L.q_origin, L.q_step, irregular, wide);
+            if (wide.ok) { // the classes by triangle slot, for whoever wants to check the limit (rt_layout_scene)
+                L.leaf_class.assign(wide.n_slots, 3);
+                for (uint32_t q = 0; q < nbn; q++)
+                    if (top_nodes[q].item != 0xFFFFFFFFu)
+                        L.leaf_class[wide.slot_of[q]] = irregular[q];
+            }
         }
     }
 

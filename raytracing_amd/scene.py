@@ -171,7 +171,8 @@ def device_layout(scene):
     """What rt_upload_scene lays out for the device, as numpy arrays (host-only; rt_layout_scene): a dict with
     `fast` and `ref` node records (n, 8) float32, `tri_pos` (slots, 12) and `spheres` (slots, 8); for flat scenes also
     `grid` (n, 4) uint32, `leaf_records` (slots, 16) float32, `grid_origin` and `grid_step` (3,) float32 (`grid` is
-    empty for other scenes), and `wide` (nodes, 16) uint32, the wide form of the fast tree (empty when there is none)."""
+    empty for other scenes), and `wide` (nodes, 16) uint32, the wide form of the fast tree (empty when there is none), with `has_distance_limit`,
+    `leaf_class` (slots,) uint8 and `limit_constants` (3, 3) float32: rows c1, 2 c2, c2 W + c3, columns the three classes."""
     nodes, tris, sph, mats = scene.nodes(), scene.tris(), scene.spheres(), scene.materials()
 
     def ptr(a):
@@ -193,6 +194,10 @@ def device_layout(scene):
            "leaf_records": grab(v.leaf_records, v.n_tri_slots if v.n_grid_nodes else 0, 16),
            "grid_origin": np.array(list(v.grid_origin), dtype=np.float32), "grid_step": np.array(list(v.grid_step), dtype=np.float32),
            "wide": (np.ctypeslib.as_array(v.wide_nodes, shape=(v.n_wide_nodes, 16)).copy() if v.n_wide_nodes
-                    else np.zeros((0, 16), dtype=np.uint32))}
+                    else np.zeros((0, 16), dtype=np.uint32)),
+           "has_distance_limit": bool(v.has_distance_limit),
+           "leaf_class": (np.ctypeslib.as_array(v.leaf_class, shape=(v.n_tri_slots,)).copy() if v.n_wide_nodes
+                          else np.zeros(0, dtype=np.uint8)),
+           "limit_constants": np.array(list(v.limit_constants), dtype=np.float32).reshape(3, 3)}
     N.hip().rt_layout_free(C.byref(v))
     return out
