@@ -2,14 +2,18 @@
 // Every thread runs a loop of independent multiply-adds (or of the wide walk's instruction mix: byte conversion,
 // multiply-add, three-way maximum); waves per SIMD and chains per thread are swept.  Prints wave-instructions per SIMD and
 // clock at the clock rate given on the command line (GHz), and lane-operations per second chip-wide.
+// valu_probe <GHz> <lanes> [mix]: one configuration with only <lanes> lanes of every wave at work -- run under the hardware
+// counters, it says what the counters report for a known number of active lanes (tools/lane_calibration.sh).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 template <int CHAINS, int MIX>
-__global__ void __launch_bounds__(256) k_valu(float *out, int iters, float a, float b) {
+__global__ void __launch_bounds__(256) k_valu(float *out, int iters, float a, float b, unsigned lanes) {
     float x[CHAINS];
+    if ((threadIdx.x & 63u) >= lanes) // the other lanes of the wave sit the loop out
+        return;
     unsigned w = threadIdx.x * 2654435761u;
 #pragma unroll
     for (int c = 0; c < CHAINS; c++)
@@ -23,6 +27,8 @@ __global__ void __launch_bounds__(256) k_valu(float *out, int iters, float a, fl
                 const float p = (float)((w >> (8 * (c & 3))) & 0xFFu);
                 const float t = __builtin_fmaf(p, a, b);
                 x[c] = fmaxf(fmaxf(x[c], t), b);
+            } else if (MIX == 3) { // a quarter-rate instruction (reciprocal) and a multiply-add
+                x[c] = __builtin_fmaf(__builtin_amdgcn_rcpf(x[c]), a, b);
             } else { // mul + add, not fused
                 x[c] = x[c] * a;
                 asm volatile("" : "+v"(x[c]));
@@ -39,15 +45,15 @@ __global__ void __launch_bounds__(256) k_valu(float *out, int iters, float a, fl
 }
 
 template <int CHAINS, int MIX>
-double run(int blocks_per_cu, int cus, int iters, float *d_out) {
+double run(int blocks_per_cu, int cus, int iters, float *d_out, unsigned lanes = 64u) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     const int blocks = blocks_per_cu * cus;
-    hipLaunchKernelGGL((k_valu<CHAINS, MIX>), dim3(blocks), dim3(256), 0, 0, d_out, iters / 10, 1.0001f, 0.5f);
+    hipLaunchKernelGGL((k_valu<CHAINS, MIX>), dim3(blocks), dim3(256), 0, 0, d_out, iters / 10, 1.0001f, 0.5f, lanes);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k_valu<CHAINS, MIX>), dim3(blocks), dim3(256), 0, 0, d_out, iters, 1.0001f, 0.5f);
+    hipLaunchKernelGGL((k_valu<CHAINS, MIX>), dim3(blocks), dim3(256), 0, 0, d_out, iters, 1.0001f, 0.5f, lanes);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
@@ -63,6 +69,15 @@ int main(int argc, char **argv) {
     float *d_out;
     (void)hipMalloc(&d_out, (size_t)cus * 8 * 256 * sizeof(float));
     const int iters = 20000;
+    if (argc > 2) { // counter calibration: one configuration, `lanes` lanes of every wave at work, under rocprofv3 --pmc
+        const unsigned lanes = (unsigned)atoi(argv[2]);
+        const int mix = argc > 3 ? atoi(argv[3]) : 0;
+        const double secs = mix == 1   ? run<8, 1>(4, cus, iters, d_out, lanes)
+                            : mix == 3 ? run<8, 3>(4, cus, iters, d_out, lanes)
+                                       : run<8, 0>(4, cus, iters, d_out, lanes);
+        printf("calibration: %u lanes per wave, mix %d, 4 waves/SIMD, %.3f ms\n", lanes, mix, secs * 1e3);
+        return 0;
+    }
     printf("%d CUs, clock taken as %.2f GHz; wave-instructions per SIMD and clock (1 / this = clocks per instruction)\n", cus, ghz);
     for (int bpc : {1, 2, 4, 8}) {
         struct { const char *name; double secs; double per_iter; } rows[] = {
