@@ -198,7 +198,9 @@ int rt_create(rt_ctx **out, int device);
  * together on device_ids[0] (peer copies over xGMI), where d_rgba of rt_trace_device must live.  rt_options.tile_rank /
  * tile_world / sample_offset keep their meaning for the context as a whole, so processes and devices can be combined.
  * rt_trace_device returns when the devices have finished their shares (the assembly is enqueued on the context's
- * stream); rt_set_pipelining(1) and rt_trace_device_noalloc are refused.  n_devices == 1 is rt_create. */
+ * stream); rt_set_pipelining(1) and rt_trace_device_noalloc are refused.  rt_trace_begin / rt_trace_end work with the
+ * tile split: every device keeps its own share of the two calls in flight, and the first device's copy stream puts each
+ * frame together as soon as the shares are complete.  n_devices == 1 is rt_create. */
 int rt_create_multi(rt_ctx **out, const int *device_ids, int n_devices);
 int rt_device_count(rt_ctx *ctx); /* devices behind the context */
 void rt_destroy(rt_ctx *ctx);
@@ -250,7 +252,8 @@ int rt_trace(rt_ctx *ctx, int width, int height, int first_sample, int n_samples
  * mean after that call.  A begun call continues from the mean of the call begun before it (or of the last ended call)
  * and leaves the last ENDED call's mean untouched, so rt_trace_discard -- or any rt_trace, rt_reset, rt_upload_scene --
  * drops what is in flight as if it had never been begun.  The bits are rt_trace's.  stats (may be NULL): counters as
- * accumulated since the previous rt_sync / rt_trace, which may include part of a call begun later; no kernel times. */
+ * accumulated since the previous rt_sync / rt_trace, which may include part of a call begun later; no kernel times.
+ * On a context over several devices: with RT_SPLIT_TILE only (RT_ERR_INVALID_ARGUMENT otherwise). */
 int rt_trace_begin(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *out_rgba_mean);
 int rt_trace_end(rt_ctx *ctx, rt_stats *stats);
 int rt_trace_discard(rt_ctx *ctx);

@@ -205,8 +205,8 @@ template <int ESTIMATOR, class Context, class App> class TraceHIPImpl : public A
     }
 
   public:
-    // Counters of the last frame.  Synchronous frames (several devices, or lookAhead off and on a multi-device context):
-    // exactly that call's, with its kernel time.  With frames computed ahead: what the device counted between this frame's
+    // Counters of the last frame.  Synchronous frames (several devices sharing a frame by samples): exactly that call's, with
+    // its kernel time.  Otherwise: what the device counted between this frame's
     // hand-over and the one before it -- over a run of frames they add up to the run's total, but a single frame's figure
     // includes whatever part of the next frames had already run; kernel_ms and launches are 0 (no timing events are taken).
     rt_stats lastStats{};
@@ -256,8 +256,9 @@ template <int ESTIMATOR, class Context, class App> class TraceHIPImpl : public A
             }
             stagingFloats = need;
         }
-        const bool single = rt_device_count(DIContext.ctx) == 1;
-        if (!single) { // several devices behind the context: synchronous calls
+        // frames are computed ahead on one device, and on several when they share a frame by tiles (the default split)
+        if (rt_device_count(DIContext.ctx) != 1 && opt.multi_split != RT_SPLIT_TILE) { // synchronous calls
+            drop();
             DIContext.check(rt_set_camera(DIContext.ctx, &cam), "rt_set_camera");
             DIContext.check(rt_set_options(DIContext.ctx, &opt), "rt_set_options");
             DIContext.check(rt_trace(DIContext.ctx, (int)w, (int)h, sampleCount, 1, staging[0], nullptr, &lastStats), "rt_trace");

@@ -28,6 +28,7 @@ constexpr int kSubQueues = 64;             // a level's path queue is 64 sub-que
 constexpr int kCounterSlots = 64, kCounterStride = 16; // statistics are added into 64 slots of 16 values, summed by the host
 constexpr int kWideStack = 16;             // entries of a lane's stack in the wide walk = interior levels of the deepest wide tree the upload accepts
 constexpr uint32_t kWideWaveMinItems = 1u << 20; // wide tree: a chunk with more pixel samples than this walks its fresh camera rays wave-synchronously first
+constexpr uint32_t kWideWaveMaxNodes = 2048; // wide records of the largest tree whose fresh camera rays are walked wave-synchronously first
 #ifndef RT_WIDE_BURST
 #define RT_WIDE_BURST 4
 #endif

@@ -84,7 +84,7 @@ struct Workspace {
     float4 *colors = nullptr, *q[2] = {nullptr, nullptr};
     unsigned int *levels = nullptr;   // per level: 64 sub-queue slots of 32 words (count, batch cursor)
     unsigned long long *deferred = nullptr; // per pixel: which samples of the chunk the camera stage queued
-    size_t colors_cap = 0, q_cap = 0; // capacities in float4
+    size_t colors_cap = 0, q_cap[2] = {0, 0}; // capacities in float4
     size_t deferred_cap = 0;          // pixels
 };
 
@@ -168,6 +168,8 @@ struct rt_ctx {
     std::vector<uint32_t *> peer_prim; // ... and for their primary-id images
     std::vector<int> kid_samples;      // sample split: samples folded into each kid's own mean since the last restart
     size_t peer_cap = 0;               // pixels the landing buffers hold
+    float4 *multi_frame = nullptr;     // where the frames of calls begun ahead (rt_trace_begin) are put together
+    size_t multi_frame_cap = 0;
     int multi_w = 0, multi_h = 0;      // frame size of the run the kids' means belong to
 };
 
@@ -255,7 +257,7 @@ void free_workspace(Workspace &ws) {
     if (ws.deferred) (void)hipFree(ws.deferred);
     ws.colors = ws.q[0] = ws.q[1] = nullptr;
     ws.deferred = nullptr;
-    ws.colors_cap = ws.q_cap = ws.deferred_cap = 0;
+    ws.colors_cap = ws.q_cap[0] = ws.q_cap[1] = ws.deferred_cap = 0;
 }
 
 inline float u2f(uint32_t u) {
@@ -548,8 +550,13 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     // (which also keeps every triangle slot within the 25 bits of a job word: the wave walk notes all its leaves)
     P.wave_camera = tuning().wave_camera != 0 && ctx->scene_bytes <= kRefillSceneBytes ? 1 : 0;
     P.compact = !pl.compact ? 0 : ctx->scene_bytes > kRefillSceneBytes ? 2 : 1; // 2: two records per trip to memory
-    if (pl.wide)
+    if (pl.wide) {
         pl.levels = 2;
+        // the wave-synchronous camera round pays only on small trees (2 426-triangle dragon, 700 wide records: 10 % faster
+        // with it; 18 520 triangles, 5 472 records: 5 % slower, and its queue of path records is most of the workspace)
+        if (ctx->n_wide > kWideWaveMaxNodes)
+            P.wave_camera = 0;
+    }
     P.npix = (uint32_t)pl.npix;
     P.cpix = (uint32_t)pl.items_per_sample;
     pl.W = W;
@@ -646,16 +653,11 @@ int launch_chunk(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t s
         if (blocks < 1)
             blocks = 1;
         dim3 grid(blocks);
-        const int v = (pl.variant & 3) * 2 + (pl.rec4 == 6 ? 1 : 0);
-        switch (v) {
-        case 0: hipLaunchKernelGGL((k_camera<false, false, 4>), grid, block, 0, stream, P); break;
-        case 1: hipLaunchKernelGGL((k_camera<false, false, 6>), grid, block, 0, stream, P); break;
-        case 2: hipLaunchKernelGGL((k_camera<false, true, 4>), grid, block, 0, stream, P); break;
-        case 3: hipLaunchKernelGGL((k_camera<false, true, 6>), grid, block, 0, stream, P); break;
-        case 4: hipLaunchKernelGGL((k_camera<true, false, 4>), grid, block, 0, stream, P); break;
-        case 5: hipLaunchKernelGGL((k_camera<true, false, 6>), grid, block, 0, stream, P); break;
-        case 6: hipLaunchKernelGGL((k_camera<true, true, 4>), grid, block, 0, stream, P); break;
-        default: hipLaunchKernelGGL((k_camera<true, true, 6>), grid, block, 0, stream, P); break;
+        switch (pl.variant & 3) {
+        case 0: hipLaunchKernelGGL((k_camera<false, false>), grid, block, 0, stream, P); break;
+        case 1: hipLaunchKernelGGL((k_camera<false, true>), grid, block, 0, stream, P); break;
+        case 2: hipLaunchKernelGGL((k_camera<true, false>), grid, block, 0, stream, P); break;
+        default: hipLaunchKernelGGL((k_camera<true, true>), grid, block, 0, stream, P); break;
         }
         RT_HIP_CHECK(ctx, hipGetLastError());
     }
@@ -775,31 +777,56 @@ int launch_fold(rt_ctx *ctx, const Plan &pl, const Workspace &ws, hipStream_t st
     return RT_OK;
 }
 
-// Gives a pipe's workspace room for chunks of `need_colors` colours and queues of `need_q4` float4 (allocates; the pipe's
-// stream is drained first when buffers have to be replaced).
-int ensure_workspace(rt_ctx *ctx, rt_ctx::Pipe &pp, size_t need_colors, size_t need_q4, size_t need_pixels) {
+// Gives a pipe's workspace room for chunks of `need_colors` colours and queues of `need_q[0]`, `need_q[1]` float4 (allocates; the
+// pipe's stream is drained first when buffers have to be replaced).
+int ensure_workspace(rt_ctx *ctx, rt_ctx::Pipe &pp, size_t need_colors, const size_t need_q[2], size_t need_pixels) {
     Workspace &ws = pp.ws;
-    if (need_colors <= ws.colors_cap && need_q4 <= ws.q_cap && need_pixels <= ws.deferred_cap)
+    if (need_colors <= ws.colors_cap && need_q[0] <= ws.q_cap[0] && need_q[1] <= ws.q_cap[1] && need_pixels <= ws.deferred_cap)
         return RT_OK;
     RT_HIP_CHECK(ctx, hipStreamSynchronize(pp.stream));
-    if (need_colors < ws.colors_cap)
-        need_colors = ws.colors_cap;
-    if (need_q4 < ws.q_cap)
-        need_q4 = ws.q_cap;
-    if (need_pixels < ws.deferred_cap)
-        need_pixels = ws.deferred_cap;
-    unsigned int *levels = ws.levels;
-    ws.levels = nullptr;
-    free_workspace(ws);
-    ws.levels = levels;
-    RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.colors, (need_colors ? need_colors : 1) * sizeof(float4)));
-    RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.q[0], (need_q4 ? need_q4 : 1) * sizeof(float4)));
-    RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.q[1], (need_q4 ? need_q4 : 1) * sizeof(float4)));
-    RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.deferred, (need_pixels ? need_pixels : 1) * sizeof(unsigned long long)));
-    ws.colors_cap = need_colors;
-    ws.q_cap = need_q4;
-    ws.deferred_cap = need_pixels;
+    if (need_colors > ws.colors_cap) {
+        if (ws.colors) (void)hipFree(ws.colors);
+        ws.colors = nullptr;
+        ws.colors_cap = 0;
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.colors, need_colors * sizeof(float4)));
+        ws.colors_cap = need_colors;
+    }
+    for (int k = 0; k < 2; k++)
+        if (need_q[k] > ws.q_cap[k]) {
+            if (ws.q[k]) (void)hipFree(ws.q[k]);
+            ws.q[k] = nullptr;
+            ws.q_cap[k] = 0;
+            RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.q[k], need_q[k] * sizeof(float4)));
+            ws.q_cap[k] = need_q[k];
+        }
+    if (need_pixels > ws.deferred_cap) {
+        if (ws.deferred) (void)hipFree(ws.deferred);
+        ws.deferred = nullptr;
+        ws.deferred_cap = 0;
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ws.deferred, need_pixels * sizeof(unsigned long long)));
+        ws.deferred_cap = need_pixels;
+    }
     return RT_OK;
+}
+
+// float4 the two queues of a chunk of `items` pixel samples need under plan `pl`.  A queue of path records takes rec4
+// float4 per record, the queue a camera stage fills one.  The wide flow uses what its two or three launches use: the
+// camera stage writes q[1]; the wave-synchronous camera round, when the chunk has one, writes the queue the re-fill
+// kernel then reads (q[0] after a camera stage, q[1] without); the re-fill kernel writes none.
+void queue_needs(const Plan &pl, size_t items, size_t need[2]) {
+    const size_t n = queue_records(items);
+    need[0] = need[1] = n * pl.rec4;
+    if (!pl.wide)
+        return;
+    need[0] = need[1] = 0;
+    const bool by_wave = pl.P.wave_camera != 0 && items > kWideWaveMinItems;
+    if (pl.camera) {
+        need[1] = n;
+        if (by_wave)
+            need[0] = n * pl.rec4;
+    } else if (by_wave) {
+        need[1] = n * pl.rec4;
+    }
 }
 
 int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim, const float4 *d_img_in = nullptr,
@@ -836,17 +863,21 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
     }
     // ---- wavefront: samples in chunks of S; per chunk one launch per bounce level (or round), then k_fold ----
     const int S = chunk_samples(pl, kMaxItems);
-    const size_t need_colors = (size_t)S * pl.items_per_sample, need_q4 = queue_records((size_t)S * pl.items_per_sample) * pl.rec4;
+    const size_t need_colors = (size_t)S * pl.items_per_sample;
+    size_t need_q[2];
+    queue_needs(pl, (size_t)S * pl.items_per_sample, need_q);
     if (timed)
         RT_HIP_CHECK(ctx, hipEventRecord(ctx->events[ctx->pending].first, ctx->stream));
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     hipStream_t last_stream = ctx->stream;
+    if (!ctx->pipelining)
+        ctx->next_pipe = 0; // calls that do not overlap start on the same pipe: one chunk per call then needs one workspace, not two
     for (int done = 0; done < count; done += S) {
         const int s_now = count - done < S ? count - done : S;
         rt_ctx::Pipe &pp = ctx->pipes[ctx->next_pipe];
         ctx->next_pipe ^= 1;
         {
-            const int wrc = ensure_workspace(ctx, pp, need_colors, need_q4, pl.items_per_sample * (size_t)((S + 63) / 64));
+            const int wrc = ensure_workspace(ctx, pp, need_colors, need_q, pl.items_per_sample * (size_t)((S + 63) / 64));
             if (wrc != RT_OK)
                 return wrc;
         }
@@ -917,7 +948,7 @@ int launch_trace_noalloc(rt_ctx *ctx, int W, int H, int first, int count, float4
     ws.q[1] = (float4 *)(base + kScratchLevelsBytes + kScratchColorsBytes + kScratchDeferredBytes + kScratchQueueBytes);
     ws.deferred_cap = kScratchMaxItems;
     ws.colors_cap = kScratchMaxItems;
-    ws.q_cap = (kScratchMaxItems + kQueueSlack) * 6;
+    ws.q_cap[0] = ws.q_cap[1] = (kScratchMaxItems + kQueueSlack) * 6;
     const int S = chunk_samples(pl, kScratchMaxItems); // S * items <= kScratchMaxItems: the colours and the `deferred` words (64 slots per owned tile and sample) fit too
     for (int done = 0; done < count; done += S) {
         const int s_now = count - done < S ? count - done : S;
@@ -1133,6 +1164,7 @@ void destroy_single(rt_ctx *ctx) {
     }
     for (float4 *p : ctx->peer_img)
         if (p) (void)hipFree(p);
+    if (ctx->multi_frame) (void)hipFree(ctx->multi_frame);
     for (uint32_t *p : ctx->peer_prim)
         if (p) (void)hipFree(p);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1181,6 +1213,29 @@ int create_single(rt_ctx **out, int device) {
 }
 
 // ------------------------------------------------------------------ several devices behind one context
+// Landing buffers on the first device of a multi-device context, one per other device, for frames of `px` pixels.
+int ensure_landing(rt_ctx *ctx, size_t px) {
+    const int n = (int)ctx->kids.size();
+    if (px <= ctx->peer_cap)
+        return RT_OK;
+    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->copy_stream)
+        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    for (int r = 1; r < n; r++) {
+        if (ctx->peer_img[r]) (void)hipFree(ctx->peer_img[r]);
+        if (ctx->peer_prim[r]) (void)hipFree(ctx->peer_prim[r]);
+        ctx->peer_img[r] = nullptr;
+        ctx->peer_prim[r] = nullptr;
+    }
+    ctx->peer_cap = 0;
+    for (int r = 1; r < n; r++) {
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->peer_img[r], px * sizeof(float4)));
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->peer_prim[r], px * sizeof(uint32_t)));
+    }
+    ctx->peer_cap = px;
+    return RT_OK;
+}
+
 // rt_create_multi: kid r renders its share of every call on its own device -- its tiles of the frame (RT_SPLIT_TILE:
 // tile k belongs to kid k % n) or its samples of the whole frame (RT_SPLIT_SAMPLE) -- into its own image; one host
 // thread per device issues the work and waits for it; the frames then travel to the first device of the list
@@ -1211,21 +1266,10 @@ int multi_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_out, 
             s = 0;
     ctx->multi_w = W;
     ctx->multi_h = H;
-    // landing buffers on the first device
-    if (px > ctx->peer_cap) {
-        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        for (int r = 1; r < n; r++) {
-            if (ctx->peer_img[r]) (void)hipFree(ctx->peer_img[r]);
-            if (ctx->peer_prim[r]) (void)hipFree(ctx->peer_prim[r]);
-            ctx->peer_img[r] = nullptr;
-            ctx->peer_prim[r] = nullptr;
-        }
-        ctx->peer_cap = 0;
-        for (int r = 1; r < n; r++) {
-            RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->peer_img[r], px * sizeof(float4)));
-            RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->peer_prim[r], px * sizeof(uint32_t)));
-        }
-        ctx->peer_cap = px;
+    {
+        const int lrc = ensure_landing(ctx, px);
+        if (lrc != RT_OK)
+            return lrc;
     }
     // shares
     std::vector<int> share(n, 0), start(n, 0);
@@ -1323,6 +1367,207 @@ int multi_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_out, 
                                (W + 7) / 8, ctx->opt.tile_rank + r * ctx->opt.tile_world, ctx->opt.tile_world * n);
         }
         RT_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return RT_OK;
+}
+
+// One call put in flight on a single-device context (rt_trace_begin; the caller holds the context's lock and has made its
+// device current): the mean moves on round the ring, the call's kernels overlap the end of the call before, and `copied`
+// of the new entry of `begun` is signalled when the call's image is complete -- and copied to out_rgba_mean, if given.
+int begin_frame(rt_ctx *ctx, int width, int height, int first_sample, int n_samples, float *out_rgba_mean) {
+    const size_t px = (size_t)width * (size_t)height;
+    if (width != ctx->img_w || height != ctx->img_h || !ctx->d_image) {
+        int rc = discard_begun(ctx);
+        if (rc == RT_OK)
+            rc = join_pipes(ctx);
+        if (rc == RT_OK)
+            rc = ensure_image(ctx, width, height);
+        if (rc != RT_OK)
+            return rc;
+    }
+    if (!ctx->copy_stream) {
+        RT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t &e : ctx->ev_copied)
+            RT_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        RT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_call, hipEventDisableTiming));
+    }
+    for (float4 *&r : ctx->ring)
+        if (!r)
+            RT_HIP_CHECK(ctx, hipMalloc((void **)&r, px * sizeof(float4)));
+    const int from = ctx->begun.empty() ? ctx->ring_at : ctx->begun.back().img, to = (from + 1) % 3;
+    // first_sample == 1 restarts the mean: the folds overwrite every owned pixel, and a share of the frame (tile split)
+    // must find the rest zero
+    if (first_sample == 1 && ctx->opt.tile_world > 1)
+        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->ring[to], 0, px * sizeof(float4), ctx->stream));
+    // the call's chunks are ordered among themselves and behind the call before (the folds chain); nothing makes the
+    // context's stream wait, so this call's kernels overlap the latency-bound end of the one before
+    const bool was = ctx->pipelining;
+    ctx->pipelining = true;
+    const int rc = launch_trace(ctx, width, height, first_sample, n_samples, ctx->ring[to], nullptr, ctx->ring[from], false);
+    ctx->pipelining = was;
+    if (rc != RT_OK)
+        return rc;
+    if (!ctx->joined && ctx->last_fold != nullptr) {
+        RT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->last_fold, 0));
+    } else {
+        RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_call, ctx->stream));
+        RT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_call, 0));
+    }
+    if (out_rgba_mean)
+        RT_HIP_CHECK(ctx, hipMemcpyAsync(out_rgba_mean, ctx->ring[to], px * sizeof(float4), hipMemcpyDeviceToHost, ctx->copy_stream));
+    hipEvent_t ev = ctx->ev_copied[ctx->next_copied];
+    ctx->next_copied ^= 1;
+    RT_HIP_CHECK(ctx, hipEventRecord(ev, ctx->copy_stream));
+    ctx->begun.push_back(rt_ctx::Begun{to, out_rgba_mean, ev});
+    return RT_OK;
+}
+
+// The oldest call in flight becomes the context's running mean (waits for it).
+int end_frame(rt_ctx *ctx) {
+    const rt_ctx::Begun b = ctx->begun.front();
+    RT_HIP_CHECK(ctx, hipEventSynchronize(b.copied));
+    ctx->begun.pop_front();
+    ctx->ring_at = b.img;
+    ctx->d_image = ctx->ring[b.img];
+    return RT_OK;
+}
+
+// The counters as they stand (a call begun later may already have added to them); added to *stats.
+int read_counters(rt_ctx *ctx, rt_stats *stats) {
+    unsigned long long slots[kCounterSlots * kCounterStride], h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    RT_HIP_CHECK(ctx, hipMemcpyAsync(slots, ctx->d_counters, sizeof(slots), hipMemcpyDeviceToHost, ctx->copy_stream));
+    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    for (int sl = 0; sl < kCounterSlots; sl++)
+        for (int k = 0; k < 8; k++)
+            h[k] += slots[sl * kCounterStride + k];
+    stats->rays += h[0];
+    stats->box_tests += h[1];
+    stats->tri_tests += h[2];
+    stats->sph_tests += h[3];
+    stats->tri_hits += h[4];
+    stats->replays += h[5];
+    return RT_OK;
+}
+
+// rt_trace_begin on several devices (tile split): every device begins the call on its own share of the frame -- its own
+// ring of means, exactly as a single-device context does -- and the first device's copy stream, once each share is complete,
+// fetches it (hipMemcpyPeerAsync), puts the frame together and sends it to the host.  One stream carries all of that for
+// every call, so one landing buffer per device and one assembled frame serve the two calls in flight.
+int multi_begin(rt_ctx *ctx, int W, int H, int first, int count, float *out_rgba_mean) {
+    const int n = (int)ctx->kids.size();
+    if (ctx->opt.multi_split != RT_SPLIT_TILE)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_trace_begin on several devices needs the tile split (RT_SPLIT_TILE)");
+    if (!ctx->has_camera)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "camera not set");
+    const size_t px = (size_t)W * (size_t)H;
+    if (!ctx->copy_stream) {
+        RT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t &e : ctx->ev_copied)
+            RT_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    {
+        const int lrc = ensure_landing(ctx, px);
+        if (lrc != RT_OK)
+            return lrc;
+    }
+    if (px > ctx->multi_frame_cap) {
+        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy_stream));
+        if (ctx->multi_frame) (void)hipFree(ctx->multi_frame);
+        ctx->multi_frame = nullptr;
+        ctx->multi_frame_cap = 0;
+        RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->multi_frame, px * sizeof(float4)));
+        ctx->multi_frame_cap = px;
+    }
+    for (int r = 0; r < n; r++) {
+        rt_ctx *k = ctx->kids[r];
+        std::lock_guard<std::mutex> lock(k->mu);
+        DeviceGuard g(k->device);
+        if (g.rc != hipSuccess)
+            return fail(ctx, RT_ERR_HIP, "hipSetDevice failed");
+        rt_options o = ctx->opt;
+        o.tile_rank = ctx->opt.tile_rank + r * ctx->opt.tile_world;
+        o.tile_world = ctx->opt.tile_world * n;
+        k->opt = o;
+        k->cam = ctx->cam;
+        k->has_camera = true;
+        const int rc = begin_frame(k, W, H, first, count, nullptr);
+        if (rc != RT_OK) {
+            std::string msg;
+            {
+                std::lock_guard<std::mutex> eg(k->err_mu);
+                msg = k->err;
+            }
+            // a call is in flight on all devices or on none: everything begun so far is dropped (this device's lock is held here)
+            if (ctx->copy_stream)
+                (void)hipStreamSynchronize(ctx->copy_stream);
+            ctx->begun.clear();
+            (void)discard_begun(k);
+            for (int q = 0; q < n; q++) {
+                if (q == r)
+                    continue;
+                rt_ctx *kq = ctx->kids[q];
+                std::lock_guard<std::mutex> ql(kq->mu);
+                DeviceGuard qg(kq->device);
+                (void)discard_begun(kq);
+            }
+            return fail(ctx, rc, "device " + std::to_string(k->device) + ": " + msg);
+        }
+    }
+    const dim3 grid((unsigned)((px + 255) / 256)), block(256);
+    for (int r = 0; r < n; r++) {
+        rt_ctx *k = ctx->kids[r];
+        const rt_ctx::Begun &kb = k->begun.back();
+        RT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->copy_stream, kb.copied, 0));
+        const float4 *src = k->ring[kb.img];
+        if (r > 0) {
+            RT_HIP_CHECK(ctx, hipMemcpyPeerAsync(ctx->peer_img[r], ctx->device, src, k->device, px * sizeof(float4), ctx->copy_stream));
+            src = ctx->peer_img[r];
+        }
+        hipLaunchKernelGGL(k_take_tiles, grid, block, 0, ctx->copy_stream, ctx->multi_frame, src, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                           (uint32_t)px, W, (W + 7) / 8, ctx->opt.tile_rank + r * ctx->opt.tile_world, ctx->opt.tile_world * n);
+        RT_HIP_CHECK(ctx, hipGetLastError());
+    }
+    RT_HIP_CHECK(ctx, hipMemcpyAsync(out_rgba_mean, ctx->multi_frame, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->copy_stream));
+    hipEvent_t ev = ctx->ev_copied[ctx->next_copied];
+    ctx->next_copied ^= 1;
+    RT_HIP_CHECK(ctx, hipEventRecord(ev, ctx->copy_stream));
+    ctx->begun.push_back(rt_ctx::Begun{-1, out_rgba_mean, ev});
+    return RT_OK;
+}
+
+int multi_end(rt_ctx *ctx, rt_stats *stats) {
+    const rt_ctx::Begun b = ctx->begun.front();
+    RT_HIP_CHECK(ctx, hipEventSynchronize(b.copied));
+    ctx->begun.pop_front();
+    if (stats)
+        std::memset(stats, 0, sizeof(*stats));
+    for (rt_ctx *k : ctx->kids) {
+        std::lock_guard<std::mutex> lock(k->mu);
+        DeviceGuard g(k->device);
+        int rc = end_frame(k); // (complete already: the frame was put together from it)
+        if (rc == RT_OK && stats)
+            rc = read_counters(k, stats);
+        if (rc != RT_OK)
+            return fail(ctx, rc, "device " + std::to_string(k->device) + ": rt_trace_end failed");
+    }
+    return RT_OK;
+}
+
+// Drops the calls in flight, on every device behind the context.
+int discard_all(rt_ctx *ctx) {
+    if (ctx->kids.empty())
+        return discard_begun(ctx);
+    if (ctx->begun.empty())
+        return RT_OK;
+    if (ctx->copy_stream)
+        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    ctx->begun.clear();
+    for (rt_ctx *k : ctx->kids) {
+        std::lock_guard<std::mutex> lock(k->mu);
+        DeviceGuard g(k->device);
+        const int rc = discard_begun(k);
+        if (rc != RT_OK)
+            return fail(ctx, rc, "device " + std::to_string(k->device) + ": rt_trace_discard failed");
     }
     return RT_OK;
 }
@@ -1455,6 +1700,12 @@ int rt_upload_scene(rt_ctx *ctx, const rt_node *nodes, uint32_t n_nodes, uint32_
         }
         return upload_layout(ctx, L);
     }
+    {
+        DeviceGuard g(ctx->device);
+        const int drc = discard_all(ctx); // look-ahead calls saw the old scene
+        if (drc != RT_OK)
+            return drc;
+    }
     for (rt_ctx *k : ctx->kids) { // replicated: every device walks its own copy
         std::lock_guard<std::mutex> klock(k->mu);
         const int rc = upload_layout(k, L);
@@ -1498,10 +1749,12 @@ int rt_reserve(rt_ctx *ctx, int width, int height, int n_samples) {
         const size_t tiles = (size_t)((width + 7) / 8) * (size_t)((height + 7) / 8);
         pl.items_per_sample = (tiles + (size_t)tile_world - 1) / (size_t)tile_world * 64;
         const int S = chunk_samples(pl, kMaxItems);
-        const size_t need_colors = (size_t)S * pl.items_per_sample, need_q4 = queue_records((size_t)S * pl.items_per_sample) * 6;
+        // (for any scene and any options: two queues of the largest records)
+        const size_t need_colors = (size_t)S * pl.items_per_sample, need_q[2] = {queue_records((size_t)S * pl.items_per_sample) * 6,
+                                                                                 queue_records((size_t)S * pl.items_per_sample) * 6};
         const int chunks = (n_samples + S - 1) / S;
         for (int p = 0; p < (chunks > 1 || c->pipelining ? 2 : 1); p++) {
-            const int rc = ensure_workspace(c, c->pipes[p], need_colors, need_q4, pl.items_per_sample * (size_t)((S + 63) / 64));
+            const int rc = ensure_workspace(c, c->pipes[p], need_colors, need_q, pl.items_per_sample * (size_t)((S + 63) / 64));
             if (rc != RT_OK)
                 return rc;
         }
@@ -1525,7 +1778,7 @@ int rt_reset(rt_ctx *ctx) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     RT_ON_DEVICE(ctx);
     {
-        const int drc = discard_begun(ctx);
+        const int drc = discard_all(ctx);
         if (drc != RT_OK)
             return drc;
         const int jrc = join_pipes(ctx);
@@ -1552,7 +1805,7 @@ int rt_trace(rt_ctx *ctx, int width, int height, int first_sample, int n_samples
     RT_ON_DEVICE(ctx);
     const size_t px = (size_t)width * (size_t)height;
     {
-        const int drc = discard_begun(ctx); // a synchronous call takes over from the last ended call
+        const int drc = discard_all(ctx); // a synchronous call takes over from the last ended call
         if (drc != RT_OK)
             return drc;
         const int jrc = join_pipes(ctx); // the image may still be the target of pipelined calls
@@ -1600,6 +1853,11 @@ int rt_trace_device(rt_ctx *ctx, int width, int height, int first_sample, int n_
             return fail(ctx, RT_ERR_NO_SCENE, "Scene is not loaded.");
         if (!d_rgba)
             return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null image");
+        {
+            const int drc = discard_all(ctx);
+            if (drc != RT_OK)
+                return drc;
+        }
         return multi_trace(ctx, width, height, first_sample, n_samples, (float4 *)d_rgba, d_primary_id,
                            ctx->opt.multi_split == RT_SPLIT_SAMPLE);
     }
@@ -1623,8 +1881,6 @@ int rt_trace_begin(rt_ctx *ctx, int width, int height, int first_sample, int n_s
     if (!ctx)
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    if (!ctx->kids.empty())
-        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_trace_begin works on a single-device context");
     if (width <= 0 || height <= 0 || (long long)width * height > 0x7FFFFFFFll || n_samples < 1 || !out_rgba_mean)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad width/height/sample count, or no output buffer");
     if (ctx->begun.size() >= 2)
@@ -1632,50 +1888,8 @@ int rt_trace_begin(rt_ctx *ctx, int width, int height, int first_sample, int n_s
     if (!ctx->has_scene)
         return fail(ctx, RT_ERR_NO_SCENE, "Scene is not loaded.");
     RT_ON_DEVICE(ctx);
-    const size_t px = (size_t)width * (size_t)height;
-    if (width != ctx->img_w || height != ctx->img_h || !ctx->d_image) {
-        int rc = discard_begun(ctx);
-        if (rc == RT_OK)
-            rc = join_pipes(ctx);
-        if (rc == RT_OK)
-            rc = ensure_image(ctx, width, height);
-        if (rc != RT_OK)
-            return rc;
-    }
-    if (!ctx->copy_stream) {
-        RT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-        for (hipEvent_t &e : ctx->ev_copied)
-            RT_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        RT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_call, hipEventDisableTiming));
-    }
-    for (float4 *&r : ctx->ring)
-        if (!r)
-            RT_HIP_CHECK(ctx, hipMalloc((void **)&r, px * sizeof(float4)));
-    const int from = ctx->begun.empty() ? ctx->ring_at : ctx->begun.back().img, to = (from + 1) % 3;
-    // first_sample == 1 restarts the mean: the folds overwrite every owned pixel, and a share of the frame (tile split)
-    // must find the rest zero
-    if (first_sample == 1 && ctx->opt.tile_world > 1)
-        RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->ring[to], 0, px * sizeof(float4), ctx->stream));
-    // the call's chunks are ordered among themselves and behind the call before (the folds chain); nothing makes the
-    // context's stream wait, so this call's kernels overlap the latency-bound end of the one before
-    const bool was = ctx->pipelining;
-    ctx->pipelining = true;
-    const int rc = launch_trace(ctx, width, height, first_sample, n_samples, ctx->ring[to], nullptr, ctx->ring[from], false);
-    ctx->pipelining = was;
-    if (rc != RT_OK)
-        return rc;
-    if (!ctx->joined && ctx->last_fold != nullptr) {
-        RT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->last_fold, 0));
-    } else {
-        RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_call, ctx->stream));
-        RT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_call, 0));
-    }
-    RT_HIP_CHECK(ctx, hipMemcpyAsync(out_rgba_mean, ctx->ring[to], px * sizeof(float4), hipMemcpyDeviceToHost, ctx->copy_stream));
-    hipEvent_t ev = ctx->ev_copied[ctx->next_copied];
-    ctx->next_copied ^= 1;
-    RT_HIP_CHECK(ctx, hipEventRecord(ev, ctx->copy_stream));
-    ctx->begun.push_back(rt_ctx::Begun{to, out_rgba_mean, ev});
-    return RT_OK;
+    return ctx->kids.empty() ? begin_frame(ctx, width, height, first_sample, n_samples, out_rgba_mean)
+                             : multi_begin(ctx, width, height, first_sample, n_samples, out_rgba_mean);
 }
 
 int rt_trace_end(rt_ctx *ctx, rt_stats *stats) {
@@ -1685,25 +1899,14 @@ int rt_trace_end(rt_ctx *ctx, rt_stats *stats) {
     if (ctx->begun.empty())
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_trace_end without rt_trace_begin");
     RT_ON_DEVICE(ctx);
-    const rt_ctx::Begun b = ctx->begun.front();
-    RT_HIP_CHECK(ctx, hipEventSynchronize(b.copied));
-    ctx->begun.pop_front();
-    ctx->ring_at = b.img;
-    ctx->d_image = ctx->ring[b.img];
+    if (!ctx->kids.empty())
+        return multi_end(ctx, stats);
+    const int rc = end_frame(ctx);
+    if (rc != RT_OK)
+        return rc;
     if (stats) { // what has run so far: a call begun later may already have added to the counters
         std::memset(stats, 0, sizeof(*stats));
-        unsigned long long slots[kCounterSlots * kCounterStride], h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        RT_HIP_CHECK(ctx, hipMemcpyAsync(slots, ctx->d_counters, sizeof(slots), hipMemcpyDeviceToHost, ctx->copy_stream));
-        RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy_stream));
-        for (int sl = 0; sl < kCounterSlots; sl++)
-            for (int k = 0; k < 8; k++)
-                h[k] += slots[sl * kCounterStride + k];
-        stats->rays = h[0];
-        stats->box_tests = h[1];
-        stats->tri_tests = h[2];
-        stats->sph_tests = h[3];
-        stats->tri_hits = h[4];
-        stats->replays = h[5];
+        return read_counters(ctx, stats);
     }
     return RT_OK;
 }
@@ -1713,7 +1916,7 @@ int rt_trace_discard(rt_ctx *ctx) {
         return RT_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lock(ctx->mu);
     RT_ON_DEVICE(ctx);
-    return discard_begun(ctx);
+    return discard_all(ctx);
 }
 
 int rt_set_stream(rt_ctx *ctx, void *hip_stream) {

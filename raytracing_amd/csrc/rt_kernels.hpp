@@ -291,7 +291,8 @@ __global__ void __launch_bounds__(256) k_trace(const KParams P) {
 }
 
 // What k_camera queues for a camera ray that got past the root box: 16 bytes -- direction and colour slot -- packed
-// densely at the start of its sub-queue's region (record i of sub-queue q at float4 index REC4 * q * sub_cap + i).  The
+// densely, one float4 each (record i of sub-queue q at float4 index q * sub_cap + i: the queue of a camera stage takes a sixth
+// of the memory of a queue of path records).  The
 // rest of the path state of a camera ray is known: origin, unit throughput, depth 0, and the RNG key of (pixel, sample).
 RT_D void read_camera_record(const KParams &P, const float4 r, Path &path, uint32_t &cidx) {
     cidx = __float_as_uint(r.w);
@@ -399,7 +400,7 @@ __global__ void __launch_bounds__(256, WALK == WALK_WAVE ? 8 : WALK == WALK_QUEU
             path.depth = 0;
             path.key = 0;
             if (live && P.camera_stage != 0 && P.level == 1) {
-                read_camera_record(P, P.q_in[4 * ((size_t)my_q * P.sub_cap) + (g - my_q * P.sub_cap)], path, cidx);
+                read_camera_record(P, P.q_in[g], path, cidx);
             } else if (live) {
                 const float4 r0 = P.q_in[4 * (size_t)g], r1 = P.q_in[4 * (size_t)g + 1], r2 = P.q_in[4 * (size_t)g + 2],
                              r3 = P.q_in[4 * (size_t)g + 3];
@@ -661,7 +662,7 @@ __global__ void __launch_bounds__(256, COMPACT == 3 ? RT_WIDE_WAVES : 1) k_refil
                     const size_t g = (size_t)my_q * P.sub_cap + (size_t)cur_b * 64u + item;
                     bool walking = false;
                     if (P.camera_stage != 0 && P.level == 1) {
-                        read_camera_record(P, P.q_in[R4 * ((size_t)my_q * P.sub_cap) + ((size_t)cur_b * 64u + item)], path, cidx);
+                        read_camera_record(P, P.q_in[g], path, cidx);
                     } else {
                         const float4 r0 = P.q_in[R4 * g], r1 = P.q_in[R4 * g + 1], r2 = P.q_in[R4 * g + 2], r3 = P.q_in[R4 * g + 3];
                         path.o = mk3(r0.x, r0.y, r0.z);
@@ -888,7 +889,7 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
             path.depth = 0;
             path.key = 0;
             if (live && P.camera_stage != 0 && P.level == 1) { // a camera ray: its walk has not started
-                read_camera_record(P, P.q_in[6 * ((size_t)my_q * P.sub_cap) + local], path, cidx);
+                read_camera_record(P, P.q_in[(size_t)my_q * P.sub_cap + local], path, cidx);
             } else if (live) {
                 const size_t g = (size_t)my_q * P.sub_cap + local;
                 const float4 r0 = P.q_in[6 * g], r1 = P.q_in[6 * g + 1], r2 = P.q_in[6 * g + 2], r3 = P.q_in[6 * g + 3],
@@ -1045,7 +1046,7 @@ __global__ void __launch_bounds__(256) k_sliced(const KParams P) {
 // pixel's `deferred` word and never touch memory again: k_fold regenerates their ray and folds the sky colour where their
 // turn in the sample order comes.  One queue reservation per tile (none for a tile that is all sky); records are
 // sample-major within it, so a batch of the next level holds neighbouring pixels of one sample.
-template <bool OLD, bool STATS, int REC4>
+template <bool OLD, bool STATS>
 __global__ void __launch_bounds__(256) k_camera(const KParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -1116,7 +1117,7 @@ __global__ void __launch_bounds__(256) k_camera(const KParams P) {
                     camera_ray(P, x, y, pixel, P.chunk_first + s0 + s, key, d);
                     const size_t slot = (size_t)base + (size_t)__builtin_popcountll(bm & below);
                     const uint32_t cidx = (uint32_t)(s0 + s) * P.cpix + j * 64u + lane;
-                    P.q_out[REC4 * ((size_t)q * P.sub_cap) + slot] = make_float4(d.x, d.y, d.z, __uint_as_float(cidx));
+                    P.q_out[(size_t)q * P.sub_cap + slot] = make_float4(d.x, d.y, d.z, __uint_as_float(cidx));
                 }
                 base += (unsigned int)__builtin_popcountll(bm);
             }

@@ -56,11 +56,17 @@ def test_begin_end_equals_synchronous_calls_and_discard_leaves_no_trace():
     ref.close()
 
 
-@pytest.mark.parametrize("devices", [None, [0, 0]])
+def _two_devices():
+    import torch
+    return [0, 1] if torch.cuda.device_count() >= 2 else [0, 0]
+
+
+@pytest.mark.parametrize("devices", [None, "two"])
 def test_plugin_frames_with_and_without_look_ahead(devices):
     """The headless frame loop over the HIP render mode: sample counts 1, 2, 3 ..., a camera move with a reset in between,
-    a resize -- the same frames with the trace method's look-ahead on and off (and over two devices, where calls are
-    synchronous)."""
+    a resize -- the same frames with the trace method's look-ahead on and off, on one device and over two (tile split: each
+    device keeps its share of the frames in flight)."""
+    devices = _two_devices() if devices == "two" else None
     product_sd_scene([WL.DRAGON_2426]).publish()
     out, rays = {}, {}
     for ahead in (False, True):

@@ -93,3 +93,45 @@ def test_multi_device_output_on_the_device_and_refusals(scene):
     with pytest.raises(R.TracerError) as e:
         R.Tracer(devices=[0, 99])
     assert e.value.code == -2
+
+
+def test_frames_begun_ahead_on_two_devices(scene):
+    """rt_trace_begin / rt_trace_end on a context over two devices (tile split): the frames of one device's synchronous
+    calls, bit for bit, two always in flight; a discard leaves no trace; the sample split refuses."""
+    import ctypes as C
+    W, H = 320, 180
+    one = R.Tracer(0)
+    one.upload(scene)
+    one.set_camera(WL.DRAGON_2426_CAMERA)
+    one.set_options(bounce_limit=6, seed=4)
+    frames = [one.trace(W, H, n, 1)[0].copy() for n in range(1, 8)]
+    one.close()
+    multi = R.Tracer(devices=device_list(2))
+    multi.upload(scene)
+    multi.set_camera(WL.DRAGON_2426_CAMERA)
+    multi.set_options(bounce_limit=6, seed=4)
+    bufs = []
+    for _ in range(3):
+        p = R.Tracer.alloc_host(W * H * 16)
+        bufs.append((p, np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(H, W, 4))))
+    multi.trace_begin(W, H, 1, 1, bufs[0][0])
+    multi.trace_begin(W, H, 2, 1, bufs[1][0])
+    with pytest.raises(R.TracerError):
+        multi.trace_begin(W, H, 3, 1, bufs[2][0])
+    for n in range(1, 5):
+        st = multi.trace_end()
+        assert st.rays > 0
+        assert np.array_equal(bits(bufs[(n - 1) % 3][1]), bits(frames[n - 1])), n
+        multi.trace_begin(W, H, n + 2, 1, bufs[(n + 1) % 3][0])
+    multi.trace_discard()                       # frames 5 and 6 were in flight
+    img, _, _ = multi.trace(W, H, 5, 1)         # the synchronous call continues from frame 4
+    assert np.array_equal(bits(img), bits(frames[4]))
+    multi.trace_begin(W, H, 6, 2, bufs[0][0])   # two samples in one call
+    multi.trace_end()
+    assert np.array_equal(bits(bufs[0][1]), bits(frames[6]))
+    multi.set_options(bounce_limit=6, seed=4, multi_split=R.SPLIT_SAMPLE)
+    with pytest.raises(R.TracerError):
+        multi.trace_begin(W, H, 1, 2, bufs[1][0])
+    for p, _ in bufs:
+        R.Tracer.free_host(p)
+    multi.close()
