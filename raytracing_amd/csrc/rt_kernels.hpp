@@ -1165,7 +1165,9 @@ __global__ void __launch_bounds__(256) k_fold(const KParams P) {
             c = sky_sample<OLD>(d);
         }
         const float nm1 = static_cast<float>((float)n - 1.f), nf = static_cast<float>(n);
-        px = make_float4((px.x * nm1 + c.x) / nf, (px.y * nm1 + c.y) / nf, (px.z * nm1 + c.z) / nf, (px.w * nm1 + c.w) / nf);
+        // (alpha: a mean of ones stays one -- (1 * (n - 1) + 1) / n is n / n while n is exact in fp32 -- without the division)
+        const float pw = (px.w == 1.0f && c.w == 1.0f && n < (1 << 24)) ? 1.0f : (px.w * nm1 + c.w) / nf;
+        px = make_float4((px.x * nm1 + c.x) / nf, (px.y * nm1 + c.y) / nf, (px.z * nm1 + c.z) / nf, pw);
     }
     P.image[pixel] = px;
 }

@@ -887,12 +887,6 @@ RT_D void wide_walk_from(const KParams &P, const GridRay g, uint32_t &cur, uint3
     while (at != kWideDone) {
         if (steps-- == 0)
             break;
-#ifdef RT_WIDE_DEBUG // lane use of the walk loop: thread-visits in `sph`, 64 per wave-visit in `trih`
-        if (STATS) {
-            cnt.sph++;
-            cnt.trih += (unsigned long long)__builtin_popcountll(__ballot(true)) == 0ull ? 0ull : (__lane_id() == (unsigned)__builtin_ctzll(__ballot(true)) ? 64ull : 0ull);
-        }
-#endif
         const uint4 *rec = P.wnodes + 4 * (size_t)at;
         const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
         flush();
