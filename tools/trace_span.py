@@ -3,13 +3,13 @@
 
 With pipelining the launches of consecutive steps overlap, so per-kernel average durations no longer add up to a step;
 what compares with bench.py's HIP-event time is the span from the first launch of the first timed step to the end of
-the last fold.  usage: trace_span.py kernel_trace.csv steps [launches_per_step=11]  (k_sliced: 10 rounds + k_fold for bounce limit 8;
-k_path / k_refill: 8 levels + k_fold = 9)"""
+the last fold.  usage: trace_span.py kernel_trace.csv steps launches_per_step  (flat scenes: k_camera + k_refill + k_fold = 3 per chunk of 64
+samples per pixel; pointer scenes: k_path per bounce level + k_fold)"""
 import csv
 import json
 import sys
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(k in r["Kernel_Name"] for k in ("k_path", "k_sliced", "k_refill", "k_fold"))]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(k in r["Kernel_Name"] for k in ("k_path", "k_sliced", "k_refill", "k_fold", "k_camera"))]
 steps = int(sys.argv[2])
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 11
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
