@@ -340,6 +340,14 @@ def main():
     options(True)
     trace_pass(0)
     counts = tr.sync()
+    # ... and, for flat scenes, by the counting variant of the walk that is timed (wide records, distance limit): scenes
+    # beyond every cache are priced by the cheaper of the two walks' bytes
+    walk_counts = None
+    if wl.estimator == R.EST_SD_LOOP and wl.scene_bytes() > MALL_BYTES:
+        options(2)
+        trace_pass(0)
+        walk_counts = tr.sync()
+        assert walk_counts.rays == counts.rays and walk_counts.tri_hits == counts.tri_hits
     # the same rays walked in the reference's own visiting order over the reference's own boxes: what the reference
     # traversal (and the CPU baseline) has to do per ray -- on 16 spp (that walk is slow), skipped for scenes where it
     # would take minutes (the million-triangle fields)
@@ -395,6 +403,16 @@ def main():
         # per pixel: the 16 B mean read and written once per step
         image_bytes = 32 * my_pixels
         alg_bytes = traversal_bytes(counts) + image_bytes
+        alg_note = "16 per slab test on the grid records, 64 per leaf test"
+        if walk_counts is not None:
+            # the timed walk: a 64-byte record of eight child boxes per step (8 B per box tested), a 64-byte leaf record per
+            # triangle test (its exact box is in the same record)
+            wide_bytes = 8 * walk_counts.box_tests + 64 * walk_counts.tri_tests + 36 * walk_counts.tri_hits + image_bytes
+            if wide_bytes < alg_bytes:
+                alg_bytes = wide_bytes
+                alg_note = ("8 per child box of a wide record, 64 per leaf test -- the walk with the distance limit, %.1f box tests per "
+                            "ray against %.1f of the walk without" % (walk_counts.box_tests / max(walk_counts.rays, 1),
+                                                                       counts.box_tests / max(counts.rays, 1)))
         alg_ops = traversal_ops(counts)
         secs = kernel_ms * 1e-3
         # hardware-counter figures of this workload, measured in separate rocprofv3 --pmc passes of one trace call and kept
@@ -439,12 +457,16 @@ def main():
                     "algorithmic_bytes_per_launch": int(alg_bytes),
                     "note": ("bytes the walk's own tests need (%s, 36 of normals per triangle hit) + the image; the scene's "
                              "records (%.0f MB) exceed every cache"
-                             % ("16 per slab test on the grid records, 64 per leaf test" if flat
+                             % (alg_note if flat
                                 else "32 per slab test, 36 per triangle test, 16 per sphere test", scene_bytes / 1e6))}
         roof["valu_frac"] = alg_ops / secs / 1e12 / VALU_PEAK_TOPS
-        roof.update({"kernel": "one step = one trace call: flat scenes k_camera + k_sliced for the rounds that fill the chip + "
-                               "k_refill for the rest (short-walk scenes: k_refill throughout); pointer scenes k_path, or "
-                               "k_refill beyond the L2s; one launch per round / bounce level and chunk of samples, + k_fold",
+        # what this GPU was measured to issue at best: 0.39 fp32 instructions per SIMD and clock with eight waves of independent
+        # multiply-adds per SIMD, 0.33 with four (tools/valu_probe.hip, profiles/r03_valu_probe.txt) -- 61.5 T lane-operations/s
+        roof["valu_peak_measured_Tops"] = 61.5
+        roof.update({"kernel": "one step = one trace call, per chunk of 64 samples: flat scenes k_camera (scenes that cover little of the "
+                               "frame) + one k_refill launch that follows every path to its end over the wide tree (small trees: "
+                               "k_sliced first, for the fresh camera rays) + k_fold; pointer scenes k_path per bounce level, or "
+                               "k_refill beyond the L2s, + k_fold",
                      "kernel_ms": kernel_ms,
                      "hbm_achieved_GBps": traffic / secs / 1e9 if traffic else None,
                      "hbm_frac": traffic / secs / 1e9 / HBM_PEAK_GBS if traffic else None,

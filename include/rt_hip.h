@@ -165,7 +165,9 @@ typedef struct rt_options {
     int32_t collect_stats; /* also count slab / triangle / sphere tests (slower kernel variant; it steps through the
                               exact 32-byte tree records, so the counts are those of the CPU restatement's walk, where
                               a trace without statistics may take the 16-byte grid records of a flat scene: more box
-                              tests, the same hits) */
+                              tests, the same hits).  2: count the walk a trace without statistics makes instead -- over
+                              a flat scene's wide records every child box tested counts as a box test, as does every
+                              exact leaf-box test; with the distance limit these are fewer than the exact walk's */
     uint32_t sample_offset; /* added to the sample index in the RNG key only: lets several contexts each
                                accumulate a mean over n samples of disjoint random streams (sample-range split) */
     int32_t traversal;      /* RT_TRAV_* */

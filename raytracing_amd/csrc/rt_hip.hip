@@ -532,7 +532,7 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     P.q_step = mk3(ctx->q_step[0], ctx->q_step[1], ctx->q_step[2]);
     // A trace that collects statistics walks the exact records: its counters then describe the walk the other kernels and
     // the CPU restatement make, test for test (the compact walk makes more box tests, with the same outcome).
-    pl.compact = pl.walk == WALK_FAST && (pl.sliced || pl.refill) && !old && (!st || tuning().compact == 2) && ctx->has_compact &&
+    pl.compact = pl.walk == WALK_FAST && (pl.sliced || pl.refill) && !old && (!st || tuning().compact == 2 || o.collect_stats == 2) && ctx->has_compact &&
                  tuning().compact != 0;
     for (int k = 0; k < 3 && pl.compact; k++) {
         const float ext = ctx->q_step[k] * 65536.0f, rel = c.position[k] - ctx->q_origin[k];
@@ -544,7 +544,7 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     // wave-synchronously to their ends (scenes within the L2s), and ONE launch of the re-fill kernel that follows every
     // path to its end over the wide tree.
     pl.wide = pl.compact && ctx->has_wide && o.traversal != RT_TRAV_FAST_SLICED && o.traversal != RT_TRAV_FAST_REFILL && o.traversal != RT_TRAV_FAST_REPLAY &&
-              tuning().wide != 0 && (!st || tuning().wide == 2);
+              tuning().wide != 0 && (!st || tuning().wide == 2 || o.collect_stats == 2);
     P.slice_quorum = (uint32_t)tuning().slice_quorum;
     // scenes within the L2s only: beyond them the scalar path, one request per wave at a time, waits far longer per record than
     // the 64 requests in flight of the lane-by-lane walk (907 k-triangle pair +19 %, 1.19 M-triangle field +8 %)

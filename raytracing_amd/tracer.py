@@ -101,7 +101,7 @@ class Tracer:
 
     def set_options(self, bounce_limit=4, estimator=EST_SD_LOOP, seed=1, jitter=0.001, tile_rank=0, tile_world=1,
                     collect_stats=False, sample_offset=0, traversal=0, multi_split=0, camera_stage=0):
-        o = N.OptionsC(bounce_limit, estimator, seed, jitter, tile_rank, tile_world, 1 if collect_stats else 0,
+        o = N.OptionsC(bounce_limit, estimator, seed, jitter, tile_rank, tile_world, int(collect_stats),
                        sample_offset, traversal, multi_split, camera_stage)
         self._check(N.hip().rt_set_options(self._ctx, C.byref(o)))
 

@@ -178,7 +178,11 @@ def test_results_do_not_depend_on_the_tuning():
                 {"RT_REFILL_TAIL": "0", "RT_SLICE": "33", "RT_TAIL_RAYS": "50000", "RT_CHUNK_SAMPLES": "64", "RT_EXTRA_ROUNDS": "-3"},
                 {"RT_COMPACT": "0", "RT_TAIL_RAYS": "1", "RT_SLICE_QUORUM": "63"},
                 # camera rays lane by lane instead of wave-synchronously, in rounds of the sliced walk
-                {"RT_WAVE_CAMERA": "0", "RT_TAIL_RAYS": "3000"}, {"RT_WAVE_CAMERA": "0", "RT_REFILL_TAIL": "0"}]
+                {"RT_WAVE_CAMERA": "0", "RT_TAIL_RAYS": "3000"}, {"RT_WAVE_CAMERA": "0", "RT_REFILL_TAIL": "0"},
+                # no wide tree (the grid records' sliced walk with its re-fill hand-over), the wide tree without its distance
+                # limit, and with the camera rays of every scene through it
+                {"RT_WIDE": "0"}, {"RT_WIDE": "0", "RT_TAIL_RAYS": "3000"}, {"RT_PRUNE": "0"}, {"RT_PRUNE": "0", "RT_WAVE_CAMERA": "0"},
+                {"RT_WAVE_CAMERA": "0", "RT_CHUNK_SAMPLES": "7"}]
     outs = []
     for env in settings:
         r = subprocess.run([sys.executable, "-c", TUNED, ROOT], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)

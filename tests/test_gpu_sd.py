@@ -259,3 +259,21 @@ def test_errors(tracer):
         t2.upload_arrays(nodes, len(nodes) - 1, product_sd_scene([WL.DRAGON_2426]).tris(), np.zeros(0), np.zeros(0), 0)
     assert e.value.code == -5
     t2.close()
+
+
+def test_counting_the_walk_that_is_timed(tracer):
+    """collect_stats = 2 counts the walk a trace without statistics makes (wide records, distance limit): the same image,
+    rays and hits as the exact walk's counting variant, fewer triangle tests (leaves beyond the limit are skipped), and box
+    tests counted per child box."""
+    ps = product_sd_scene([WL.DRAGON_18520])
+    tracer.upload(ps)
+    tracer.set_camera(WL.DRAGON_18520_CAMERA)
+    out = {}
+    for mode in (0, 1, 2):
+        tracer.set_options(bounce_limit=6, seed=3, collect_stats=mode)
+        img, _, st = tracer.trace(320, 180, 1, 4)
+        out[mode] = (img.copy(), st)
+    assert np.array_equal(bits(out[0][0]), bits(out[1][0])) and np.array_equal(bits(out[0][0]), bits(out[2][0]))
+    assert out[1][1].rays == out[2][1].rays == out[0][1].rays and out[1][1].tri_hits == out[2][1].tri_hits
+    assert 0 < out[2][1].tri_tests < out[1][1].tri_tests
+    assert out[2][1].box_tests > 0 and out[0][1].box_tests == 0
