@@ -318,6 +318,93 @@ def test_grid_walk_never_prunes_what_the_exact_walk_keeps():
         assert kept > 1000 and pruned_by_grid > 100 * 300    # the rays do meet the scene, and the grid does prune
 
 
+def _wide_leaves_met(wide, origin, step, o, inv):
+    """The wide walk without a distance limit, as the kernel evaluates it (wide_walk_from in rt_walks.hpp): per node the
+    frame a = ldexp(A, shift), b = fma(org, A, B) on the ray's grid slopes (grid_axis), per child t = fma(plane byte, a, b),
+    slab test against (1e-6, +inf).  Returns the set of triangle slots whose leaves the walk notes."""
+    f = np.float32
+    A, B = np.zeros(3, f), np.zeros(3, f)
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        for k in range(3):
+            if abs(inv[k]) > 1e25:
+                A[k] = f(np.copysign(f(1e30), inv[k]))
+                B[k] = f(-f(f(o[k] - origin[k]) / step[k]) * A[k])
+            else:
+                A[k] = f(step[k] * inv[k])
+                B[k] = f(f(origin[k] - o[k]) * inv[k])
+    fma = lambda x, a, b: (np.asarray(x, np.float64) * np.float64(a) + np.float64(b)).astype(f)
+    met, stack = set(), [0]
+    with np.errstate(invalid="ignore", over="ignore"):
+        while stack:
+            rec = wide[stack.pop()]
+            planes = rec[:12].astype(np.uint32)
+            org = (float(rec[12] & 0xFFFF), float(rec[12] >> 16), float(rec[13] & 0xFFFF))
+            sh = (int((rec[13] >> 16) & 15), int((rec[13] >> 20) & 15), int((rec[13] >> 24) & 15))
+            n_int, n_all = int((rec[15] >> 24) & 15), int(rec[15] >> 28)
+            tmin, tmax = np.full(8, f(1e-6)), np.full(8, f(np.inf))
+            for k in range(3):
+                a, b = f(np.ldexp(A[k], sh[k])), fma(org[k], A[k], B[k])
+                lo8 = np.array([(int(planes[4 * k + (i >> 2)]) >> (8 * (i & 3))) & 255 for i in range(8)], f)
+                hi8 = np.array([(int(planes[4 * k + 2 + (i >> 2)]) >> (8 * (i & 3))) & 255 for i in range(8)], f)
+                t0, t1 = fma(lo8, a, b), fma(hi8, a, b)
+                near, far = (t1, t0) if A[k] < 0 else (t0, t1)
+                tmin, tmax = np.fmax(tmin, near), np.fmin(tmax, far)
+            hit = tmax > tmin
+            for i in range(n_all):
+                if hit[i]:
+                    if i < n_int:
+                        stack.append(int(rec[14]) + i)
+                    else:
+                        met.add(int(rec[15] & 0xFFFFFF) + i - n_int)
+    return met
+
+
+def test_wide_walk_never_prunes_a_leaf_the_ray_meets():
+    """Conservativeness of the wide records under the kernel's own fp32 arithmetic (two roundings per plane: the node's
+    frame, then the plane): every leaf whose EXACT box a ray meets is among the leaves the wide walk notes -- rays from the
+    surface, from a camera up to 30 grid extents away, along the coordinate axes and nearly along them."""
+    rng = np.random.default_rng(11)
+    tris, _ = objparse.load_obj(WL.CYLINDER)
+    scenes = [R.SdScene().load_obj(WL.DRAGON_2426).finalize(),
+              R.SdScene().add_model(tris).add_model(WL.ground_quad(y=-1.0, x0=-200.0, x1=200.0, z0=-200.0, z1=200.0)).finalize()]
+    f = np.float32
+    for scene in scenes:
+        lay = R.device_layout(scene)
+        wide, rec = lay["wide"], lay["leaf_records"]
+        assert len(wide) > 0
+        origin, step = lay["grid_origin"], lay["grid_step"]
+        leaf_lo = np.concatenate([rec[:, 9:11], rec[:, 12:13]], 1).astype(f)
+        leaf_hi = rec[:, 13:16].astype(f)
+        root_lo, root_hi = leaf_lo.min(0).astype(np.float64), leaf_hi.max(0).astype(np.float64)
+        ext = step.astype(np.float64) * 65536.0
+        met_exact = met_wide = 0
+        for i in range(200):
+            if i % 3 == 0:      # from a point of a leaf box towards anywhere
+                j = rng.integers(len(rec))
+                o = (leaf_lo[j] + (leaf_hi[j] - leaf_lo[j]) * rng.random(3)).astype(f)
+            elif i % 3 == 1:    # from a camera far outside, towards the scene
+                o = (root_lo + ext * rng.uniform(-30.0, 31.0, 3)).astype(f)
+            else:               # from just outside the root box
+                o = (root_lo + (root_hi - root_lo) * rng.uniform(-0.2, 1.2, 3)).astype(f)
+            target = root_lo + (root_hi - root_lo) * rng.random(3)
+            d = (target - o.astype(np.float64)) if i % 3 else rng.normal(size=3)
+            d = (d / np.linalg.norm(d)).astype(f)
+            if i % 10 == 7:
+                d[rng.integers(3)] = f(0.0)
+            if i % 10 == 8:
+                d = np.zeros(3, f); d[rng.integers(3)] = f(rng.choice([-1.0, 1.0]))
+            if i % 10 == 9:
+                d[rng.integers(3)] = f(rng.choice([-1.0, 1.0]) * 1e-30)
+            with np.errstate(divide="ignore"):
+                inv = (f(1.0) / d).astype(f)
+            exact = set(np.nonzero(_slab_pass(leaf_lo, leaf_hi, o, inv))[0].tolist())
+            noted = _wide_leaves_met(wide, origin, step, o, inv)
+            assert exact <= noted, (i, o, d, sorted(exact - noted)[:5])
+            met_exact += len(exact)
+            met_wide += len(noted)
+        assert met_exact > 300 and met_wide < 40 * met_exact + 200 * 64  # the rays meet the scene, and the wide boxes prune
+
+
 def test_pointer_scenes_have_no_grid_records():
     check_grid(R.device_layout(WL.build_old_scene(WL.rtiow_spheres()).build()), False)
     tris, _ = objparse.load_obj(WL.CYLINDER)
