@@ -29,10 +29,14 @@ constexpr int kCounterSlots = 64, kCounterStride = 16; // statistics are added i
 constexpr int kWideStack = 16;             // entries of a lane's stack in the wide walk = interior levels of the deepest wide tree the upload accepts
 constexpr uint32_t kWideWaveMinItems = 1u << 20; // wide tree: a chunk with more pixel samples than this walks its fresh camera rays wave-synchronously first
 constexpr uint32_t kWideWaveMaxNodes = 2048; // wide records of the largest tree whose fresh camera rays are walked wave-synchronously first
-#ifndef RT_WIDE_BURST
-#define RT_WIDE_BURST 4
-#endif
-constexpr int kWideBurst = RT_WIDE_BURST;              // nodes a lane of the wide walk visits between two looks at the wave's state
+// Nodes a lane of the wide walk visits between two looks at the wave's state, by what a random ray through the scene's box
+// visits (the sum of the wide nodes' areas over the root's, measured at upload).  Short walks -- a mesh on a ground quad that
+// fills the view -- finish inside a long burst and their lanes wait for its end; long walks pay every look with the ballots
+// and the list check.  Swept 2 / 3 / 4 / 6 on four scenes: dragon on a ground quad (1.1 visits, within the L2s) 24.9 / 25.3 /
+// 26.4 / 28.7 ms per 128 spp, the same with the 889 k-triangle dragon beside it (beyond the L2s) level from 2 to 4, bare
+// dragon (10.4) 18.5 / 18.0 / 17.85 / 17.65 per 256 spp, 1.19 M-triangle field (11.8) 36.6 / 35.8 / 35.3 / 34.8 per 64 spp.
+constexpr int kWideBurst = 4, kWideBurstShort = 2, kWideBurstLong = 6;
+constexpr double kWideShortVisits = 2.0, kWideLongVisits = 10.0;
 constexpr int kMaxLevels = 64;             // bounce levels a wavefront trace can launch (bounce_limit <= 62)
 constexpr uint32_t kTailRays = 256u << 10;  // a level with no more rays than this follows every path to its end in one launch
 constexpr uint32_t kSlice = 128;            // k_sliced: records a ray is taken further per round
@@ -53,6 +57,7 @@ struct KParams {
     const uint4 *cnodes;       // compact fast tree (flat scenes): 16 bytes per node, see SceneLayout::cn
     const float4 *leaf_boxes;  // ... and its leaves: triangle and exact box, 4 x float4 per triangle slot
     const uint4 *wnodes;       // wide fast tree (flat scenes): 64 bytes per node of up to eight children, see build_wide
+    int wide_burst;            // ... nodes a lane visits per burst (kWideBurst and its neighbours)
     uint32_t wide_depth;       // ... and the entries a lane's stack needs for it (interior levels below the root, at least 1)
     int prune;                 // the wide walk keeps a distance limit (the scene's leaves allow one, see LeafShape in scene_layout.hpp)
     float prune_c1[3], prune_c2x2[3], prune_c3[3]; // ... its constants by leaf class: c1, 2 c2, c2 W + c3

@@ -105,6 +105,7 @@ struct rt_ctx {
     float4 *d_wnodes = nullptr;                          // ... and its wide form (SceneLayout::wn)
     bool has_wide = false;
     uint32_t n_wide = 0, wide_depth = 1;
+    double wide_visits = 0.0; // records of the wide tree a random ray through the root box visits
     bool can_prune = false;
     float prune_c[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; // c1[3], 2 c2[3], c2 W + c3 [3]
     float q_origin[3] = {0, 0, 0}, q_step[3] = {1, 1, 1};
@@ -245,6 +246,7 @@ void free_scene(rt_ctx *c) {
     c->d_cnodes = c->d_leaf_boxes = c->d_wnodes = nullptr;
     c->has_compact = c->has_wide = c->can_prune = false;
     c->n_wide = 0;
+    c->wide_visits = 0.0;
     c->fast_visits = 0.0;
     c->d_nodes = c->d_tri_pos = c->d_tri_nrm = c->d_spheres = c->d_mats = nullptr;
     c->n_nodes = 0;
@@ -326,6 +328,7 @@ struct Tuning {
     int wave_camera = 1; // RT_WAVE_CAMERA=0: camera rays walk lane by lane like every other ray
     int wide = 1;        // RT_WIDE=0: no walk takes the wide tree; 2: traces that collect statistics take it too
     int prune = 1;       // RT_PRUNE=0: the wide walk keeps no distance limit
+    int wide_burst = 0;  // RT_WIDE_BURST=<n>: nodes per burst of the wide walk (0: by the scene, see kWideBurst)
     int lds_pad = 0; // RT_LDS_PAD: bytes of unused LDS added to every path-kernel block (fewer blocks per CU: occupancy experiments)
 };
 const Tuning &tuning() {
@@ -350,6 +353,7 @@ const Tuning &tuning() {
         v.wave_camera = (int)env("RT_WAVE_CAMERA", 0, 1, 1);
         v.wide = (int)env("RT_WIDE", 0, 2, 1);
         v.prune = (int)env("RT_PRUNE", 0, 1, 1);
+        v.wide_burst = (int)env("RT_WIDE_BURST", 0, 64, 0);
         return v;
     }();
     return t;
@@ -521,6 +525,10 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     P.cnodes = (const uint4 *)ctx->d_cnodes;
     P.wnodes = (const uint4 *)ctx->d_wnodes;
     P.wide_depth = ctx->wide_depth;
+    P.wide_burst = tuning().wide_burst != 0                                                      ? tuning().wide_burst
+                   : ctx->wide_visits < kWideShortVisits && ctx->scene_bytes <= kRefillSceneBytes ? kWideBurstShort
+                   : ctx->wide_visits >= kWideLongVisits                                           ? kWideBurstLong
+                                                                                                   : kWideBurst;
     P.prune = ctx->can_prune && tuning().prune != 0 ? 1 : 0;
     for (int k = 0; k < 3; k++) {
         P.prune_c1[k] = ctx->prune_c[k];
@@ -1089,6 +1097,7 @@ int upload_layout(rt_ctx *ctx, const SceneLayout &L) {
             }
             ctx->has_wide = true;
             ctx->n_wide = L.n_wide;
+            ctx->wide_visits = L.wide_visits;
             ctx->wide_depth = L.wide_depth > 0 ? L.wide_depth : 1u;
             ctx->can_prune = L.prune;
             for (int k = 0; k < 3; k++) {

@@ -704,7 +704,7 @@ __global__ void __launch_bounds__(256, COMPACT == 3 ? RT_WIDE_WAVES : 1) k_refil
         for (;;) {
             if constexpr (WIDE) {
                 if (has && w.idx < n)
-                    wide_walk_from<STATS>(P, grid, w.idx, sp, stk, kWideBurst, closest_so_far(), dmax, inv_dmax, cnt,
+                    wide_walk_from<STATS>(P, grid, w.idx, sp, stk, P.wide_burst, closest_so_far(), dmax, inv_dmax, cnt,
                                       [&](const uint32_t k) { return atomicAdd(&J.count, k); },
                                       [&](const uint32_t j, const uint32_t slot) { note_leaf<STATS>(P, lane, j, slot, path, J, best, bpos, bm, cnt); });
             } else if constexpr (COMPACT != 0) {
