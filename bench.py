@@ -217,6 +217,12 @@ def main():
         raise SystemExit("--gpus must be at least 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
+    # The one JSON line is all that goes to this process's standard output: libraries print banners there while they
+    # initialise (RCCL its version, gloo its connections), so file descriptor 1 points at standard error from here on and the
+    # line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get("RT_BENCH_WATCHDOG"):  # dump every thread's stack if the run is still going after that many seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
@@ -562,7 +568,8 @@ def main():
             cb["gpu_counts_match_oracle"] = bool((gst.rays, gst.box_tests, gst.tri_tests, gst.sph_tests) ==
                                                  (ost.rays, ost.box_tests, ost.tri_tests, ost.sph_tests))
             out["cpu_baseline"] = cb
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     tr.close()
     if grouped:
         dist.destroy_process_group()
