@@ -250,3 +250,37 @@ def test_wave_walked_camera_batches_against_the_oracle(tracer):
         assert np.array_equal(prim, oprim), stats
         assert st.rays == ost.rays, stats
         assert np.array_equal(bits(img), bits(oimg)), stats
+
+
+FULL_SIZE = r"""
+import hashlib, sys
+sys.path.insert(0, sys.argv[1])
+import raytracing_amd as R
+from raytracing_amd import workloads as WL
+for name, spp in (("dragon18520_1080p", 16), ("dragon18520_full_ground_1080p", 4), ("dragon_field_k8_1080p", 4)):
+    wl = WL.make_workload(name)
+    t = R.Tracer(0)
+    t.upload(wl.scene)
+    t.set_camera(wl.camera)
+    t.set_options(bounce_limit=wl.bounce_limit, estimator=wl.estimator, seed=wl.seed, jitter=wl.jitter)
+    img, prim, st = t.trace(wl.width, wl.height, 1, spp, want_primary=True)
+    print(name, st.rays, st.replays, hashlib.sha256(img.tobytes()).hexdigest(), hashlib.sha256(prim.tobytes()).hexdigest())
+    t.close()
+"""
+
+
+def test_wide_walk_and_its_distance_limit_at_full_size():
+    """The bench workloads at 1920x1080 -- 33 M to 133 M camera rays and their bounces each -- under the default walk (wide
+    records, distance limit), without the limit and without the wide records (the grid records' walk): the same image and
+    the same primary ids, byte for byte.  Each setting in a process of its own (the switches are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"RT_PRUNE": "0"}, {"RT_WIDE": "0"}):
+        r = subprocess.run([sys.executable, "-c", FULL_SIZE, root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (env, r.stderr[-2000:])
+        outs.append(r.stdout.strip().splitlines())
+    assert len(outs[0]) == 3
+    assert outs[1] == outs[0] and outs[2] == outs[0]
