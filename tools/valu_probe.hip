@@ -27,6 +27,15 @@ __global__ void __launch_bounds__(256) k_valu(float *out, int iters, float a, fl
                 const float p = (float)((w >> (8 * (c & 3))) & 0xFFu);
                 const float t = __builtin_fmaf(p, a, b);
                 x[c] = fmaxf(fmaxf(x[c], t), b);
+            } else if (MIX == 4) { // packed multiply-add: two results per instruction (x[c] holds the sum of the pair)
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                static_assert(CHAINS % 2 == 0, "pairs");
+                if (c % 2 == 0) {
+                    v2f p = {x[c], x[c + 1]};
+                    p = __builtin_elementwise_fma(p, (v2f){a, a}, (v2f){b, b});
+                    x[c] = p.x;
+                    x[c + 1] = p.y;
+                }
             } else if (MIX == 3) { // a quarter-rate instruction (reciprocal) and a multiply-add
                 x[c] = __builtin_fmaf(__builtin_amdgcn_rcpf(x[c]), a, b);
             } else { // mul + add, not fused
@@ -85,6 +94,7 @@ int main(int argc, char **argv) {
             {"fma x2 chains", run<2, 0>(bpc, cus, iters, d_out), 2.0},
             {"cvt+fma+max3 x8", run<8, 1>(bpc, cus, iters, d_out), 24.0 + 2.0},
             {"mul,add x8", run<8, 2>(bpc, cus, iters, d_out), 16.0},
+            {"pk_fma x4 (8 results)", run<8, 4>(bpc, cus, iters, d_out), 4.0},
         };
         for (auto &r : rows) {
             const double wave_instr = (double)bpc * cus * 4 * iters * r.per_iter; // 4 waves per block
