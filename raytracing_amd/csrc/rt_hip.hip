@@ -375,6 +375,57 @@ struct Plan {
 
 // Part of the frame covered by the projection of the scene's root box (the bounding rectangle of its eight corners in
 // the camera's uv coordinates, Camera.hpp:33-47), 1 when a corner lies behind the camera.
+// The 8x8 tiles of a W x H frame outside which NO camera ray can meet the scene's root box, jitter included: the box
+// projects into the bounding rectangle of its eight corners' projections (all in front of the camera, else the whole frame
+// is returned); a jittered direction d = dir0 + j, |j| <= js sqrt(3) =: e, moves the ray's slope in camera space by at most
+// 2 e / (z0 (z0 - e)), z0 = focal / |(w/2, h/2, focal)| the smallest forward component of a unit view direction -- a few
+// pixels for the reference's 0.001 -- and the rectangle is widened by one and a half times that, two pixels and one more
+// tile (the slab test's own rounding is nine orders of magnitude below a tile).
+void root_box_tiles(const rt_ctx *ctx, int W, int H, float jitter, int out[4]) {
+    const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+    out[0] = out[1] = 0;
+    out[2] = tiles_x - 1;
+    out[3] = tiles_y - 1;
+    const rt_camera &c = ctx->cam;
+    const f3 pos = mk3(c.position[0], c.position[1], c.position[2]);
+    const f3 z = normalize3(mk3(c.look_at[0], c.look_at[1], c.look_at[2]) - pos);
+    const f3 x = normalize3(cross3(mk3(0.f, 1.f, 0.f), z));
+    const f3 y = cross3(z, x);
+    const double f = c.focal_length, w = c.width, h = c.height;
+    if (!(f > 0.0) || !(w > 0.0) || !(h > 0.0) || !(jitter >= 0.0f))
+        return;
+    const double z0 = f / std::sqrt(w * w / 4 + h * h / 4 + f * f), e = (double)jitter * 1.7320508075688772 * 1.0001;
+    if (!(e < z0 / 2))
+        return;
+    const double slope = 2.0 * e / (z0 * (z0 - e));
+    const double mx = 1.5 * W * f * slope / w + 2.0, my = 1.5 * H * f * slope / h + 2.0;
+    double u0 = 1e30, u1 = -1e30, v0 = 1e30, v1 = -1e30;
+    for (int k = 0; k < 8; k++) {
+        const f3 r = mk3(ctx->root_box[(k & 1) ? 3 : 0], ctx->root_box[(k & 2) ? 4 : 1], ctx->root_box[(k & 4) ? 5 : 2]) - pos;
+        const double cz = (double)r.x * z.x + (double)r.y * z.y + (double)r.z * z.z;
+        if (!(cz > 1e-4 * (std::fabs((double)r.x) + std::fabs((double)r.y) + std::fabs((double)r.z)) + 1e-30))
+            return; // a corner beside or behind the camera: no rectangle
+        const double cx = (double)r.x * x.x + (double)r.y * x.y + (double)r.z * x.z, cy = (double)r.x * y.x + (double)r.y * y.y + (double)r.z * y.z;
+        const double u = (-cx * f / cz + w / 2) / w, v = (cy * f / cz + h / 2) / h;
+        if (!(u == u) || !(v == v) || !(std::fabs(u) < 1e6) || !(std::fabs(v) < 1e6))
+            return;
+        u0 = u < u0 ? u : u0;
+        u1 = u > u1 ? u : u1;
+        v0 = v < v0 ? v : v0;
+        v1 = v > v1 ? v : v1;
+    }
+    // pixel x has u = x / W (CPUImageData::uvAt, Renderer/TraceMethods.hpp:30)
+    const double x0 = std::floor(u0 * W - mx), x1 = std::ceil(u1 * W + mx), y0 = std::floor(v0 * H - my), y1 = std::ceil(v1 * H + my);
+    auto tile_of = [](double p, int n_tiles, int extra) {
+        const double t = std::floor(p / 8.0) + extra;
+        return (int)(t < -1.0 ? -1.0 : t > (double)n_tiles ? (double)n_tiles : t);
+    };
+    out[0] = tile_of(x0, tiles_x, -1);
+    out[1] = tile_of(y0, tiles_y, -1);
+    out[2] = tile_of(x1, tiles_x, 1);
+    out[3] = tile_of(y1, tiles_y, 1);
+}
+
 double root_box_coverage(const rt_ctx *ctx) {
     const rt_camera &c = ctx->cam;
     const f3 pos = mk3(c.position[0], c.position[1], c.position[2]);
@@ -509,6 +560,14 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
     if (pl.camera && pl.levels + 1 > kMaxLevels - 1)
         pl.camera = false;
     P.camera_stage = pl.camera ? 1 : 0;
+    {
+        int tiles[4];
+        root_box_tiles(ctx, W, H, o.jitter, tiles);
+        P.cam_tx0 = tiles[0];
+        P.cam_ty0 = tiles[1];
+        P.cam_tx1 = tiles[2];
+        P.cam_ty1 = tiles[3];
+    }
     P.deferred = nullptr;
     // Slice length: 32 ... 192 records swept on bare meshes, fields and meshes on a ground quad (128 is best or level with
     // the best everywhere, now that a wave ends its slice when 16 or fewer of its lanes still walk).

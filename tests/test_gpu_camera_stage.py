@@ -164,3 +164,27 @@ def test_few_tiles_many_samples_per_chunk(tracer, dragon, size):
             img, prim, st = tracer.trace(w, h, 1, 512, want_primary=True)
             assert st.rays == ost.rays, (trav, stage)
             assert np.array_equal(prim, oprim) and np.array_equal(bits(img), bits(oimg)), (trav, stage)
+
+
+@pytest.mark.parametrize("jitter", [0.001, 0.02, 0.2])
+def test_tiles_that_cannot_see_the_scene_are_skipped_safely(tracer, dragon, jitter):
+    """The camera stage leaves out the tiles outside the widened projection of the scene's box: with the scene in a corner
+    of the frame, partly outside it, straight ahead and seen from far away -- and with jitter up to two hundred times the
+    reference's, which widens the projection (and at 0.2 switches the shortcut off) -- the frames are those of the fused
+    first launch, bit for bit, and the ray counts agree."""
+    ps, _ = dragon
+    tracer.upload(ps)
+    cams = [R.Camera(1.0, (0.0, 0.10, 0.9), 2.0, 16.0 / 9.0, (0.45, 0.30, -0.014)),      # scene in the lower left corner
+            R.Camera(1.0, (0.0, 0.10, 0.9), 2.0, 16.0 / 9.0, (-0.9, -0.35, -0.014)),     # partly outside the frame
+            R.Camera(1.0, (0.0, 0.10, 3.0), 2.0, 16.0 / 9.0, (-0.006, 0.073, -0.014)),   # small, in the middle
+            R.Camera(0.4, (0.3, 0.25, 0.6), 2.0, 16.0 / 9.0, (-0.006, 0.073, -0.014))]   # wide angle, from the side
+    for cam in cams:
+        tracer.set_camera(cam)
+        out = {}
+        for stage in (R.CAMERA_SEPARATE, R.CAMERA_FUSED):
+            tracer.set_options(bounce_limit=3, seed=11, jitter=jitter, camera_stage=stage)
+            out[stage] = tracer.trace(640, 360, 1, 3, want_primary=True)
+        (ia, pa, sa), (ib, pb, sb) = out[R.CAMERA_SEPARATE], out[R.CAMERA_FUSED]
+        assert np.array_equal(pa, pb) and np.array_equal(bits(ia), bits(ib))
+        assert sa.rays == sb.rays
+        assert (pa != R.MISS).sum() > 50          # the scene is in the frame
