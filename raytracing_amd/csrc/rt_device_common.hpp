@@ -59,6 +59,7 @@ struct KParams {
     const uint4 *wnodes;       // wide fast tree (flat scenes): 64 bytes per node of up to eight children, see build_wide
     int wide_burst;            // ... nodes a lane visits per burst (kWideBurst and its neighbours)
     int cam_tx0, cam_ty0, cam_tx1, cam_ty1; // camera stage: the 8x8 tiles (inclusive range) outside which no camera ray can meet the scene's box
+    const uint8_t *cam_mask;   // ... and, within it, one byte per tile of the frame: 0 = no camera ray of the tile can meet a box of the scene's cut (null: no mask)
     uint32_t wide_depth;       // ... and the entries a lane's stack needs for it (interior levels below the root, at least 1)
     int prune;                 // the wide walk keeps a distance limit (the scene's leaves allow one, see LeafShape in scene_layout.hpp)
     float prune_c1[3], prune_c2x2[3], prune_c3[3]; // ... its constants by leaf class: c1, 2 c2, c2 W + c3

@@ -31,6 +31,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <type_traits>
 #include <cmath>
@@ -117,6 +118,18 @@ struct rt_ctx {
     bool fast_exact = true; // the uploaded tree's interior boxes contain their children's (see build_layout)
     double expected_visits = 0.0; // sum of node box areas / root box area: nodes a random ray through the root meets
     float root_box[6] = {0, 0, 0, 0, 0, 0}; // box of the fast tree's root record: pMin.xyz, pMax.xyz
+    // camera stage: the scene's cut (host copy), and the tile mask of the last (camera, frame size, jitter, scene) it was made for
+    std::vector<float> cut_boxes;
+    uint8_t *d_cam_mask = nullptr;
+    size_t cam_mask_cap = 0;
+    struct MaskKey {
+        rt_camera cam;
+        int W, H;
+        float jitter;
+        unsigned long long scene;
+    } mask_key{};
+    bool mask_valid = false, mask_usable = false;
+    unsigned long long scene_version = 0;
     rt_camera cam;
     bool has_camera = false;
     rt_options opt;
@@ -329,6 +342,7 @@ struct Tuning {
     int wide = 1;        // RT_WIDE=0: no walk takes the wide tree; 2: traces that collect statistics take it too
     int prune = 1;       // RT_PRUNE=0: the wide walk keeps no distance limit
     int wide_burst = 0;  // RT_WIDE_BURST=<n>: nodes per burst of the wide walk (0: by the scene, see kWideBurst)
+    int tile_mask = 1;   // RT_TILE_MASK=0: the camera stage tests every tile inside the projection of the scene's box
     int lds_pad = 0; // RT_LDS_PAD: bytes of unused LDS added to every path-kernel block (fewer blocks per CU: occupancy experiments)
 };
 const Tuning &tuning() {
@@ -354,6 +368,7 @@ const Tuning &tuning() {
         v.wide = (int)env("RT_WIDE", 0, 2, 1);
         v.prune = (int)env("RT_PRUNE", 0, 1, 1);
         v.wide_burst = (int)env("RT_WIDE_BURST", 0, 64, 0);
+        v.tile_mask = (int)env("RT_TILE_MASK", 0, 1, 1);
         return v;
     }();
     return t;
@@ -375,55 +390,106 @@ struct Plan {
 
 // Part of the frame covered by the projection of the scene's root box (the bounding rectangle of its eight corners in
 // the camera's uv coordinates, Camera.hpp:33-47), 1 when a corner lies behind the camera.
-// The 8x8 tiles of a W x H frame outside which NO camera ray can meet the scene's root box, jitter included: the box
-// projects into the bounding rectangle of its eight corners' projections (all in front of the camera, else the whole frame
-// is returned); a jittered direction d = dir0 + j, |j| <= js sqrt(3) =: e, moves the ray's slope in camera space by at most
-// 2 e / (z0 (z0 - e)), z0 = focal / |(w/2, h/2, focal)| the smallest forward component of a unit view direction -- a few
-// pixels for the reference's 0.001 -- and the rectangle is widened by one and a half times that, two pixels and one more
-// tile (the slab test's own rounding is nine orders of magnitude below a tile).
-void root_box_tiles(const rt_ctx *ctx, int W, int H, float jitter, int out[4]) {
-    const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
-    out[0] = out[1] = 0;
-    out[2] = tiles_x - 1;
-    out[3] = tiles_y - 1;
-    const rt_camera &c = ctx->cam;
-    const f3 pos = mk3(c.position[0], c.position[1], c.position[2]);
-    const f3 z = normalize3(mk3(c.look_at[0], c.look_at[1], c.look_at[2]) - pos);
-    const f3 x = normalize3(cross3(mk3(0.f, 1.f, 0.f), z));
-    const f3 y = cross3(z, x);
-    const double f = c.focal_length, w = c.width, h = c.height;
-    if (!(f > 0.0) || !(w > 0.0) || !(h > 0.0) || !(jitter >= 0.0f))
-        return;
-    const double z0 = f / std::sqrt(w * w / 4 + h * h / 4 + f * f), e = (double)jitter * 1.7320508075688772 * 1.0001;
-    if (!(e < z0 / 2))
-        return;
-    const double slope = 2.0 * e / (z0 * (z0 - e));
-    const double mx = 1.5 * W * f * slope / w + 2.0, my = 1.5 * H * f * slope / h + 2.0;
-    double u0 = 1e30, u1 = -1e30, v0 = 1e30, v1 = -1e30;
-    for (int k = 0; k < 8; k++) {
-        const f3 r = mk3(ctx->root_box[(k & 1) ? 3 : 0], ctx->root_box[(k & 2) ? 4 : 1], ctx->root_box[(k & 4) ? 5 : 2]) - pos;
-        const double cz = (double)r.x * z.x + (double)r.y * z.y + (double)r.z * z.z;
-        if (!(cz > 1e-4 * (std::fabs((double)r.x) + std::fabs((double)r.y) + std::fabs((double)r.z)) + 1e-30))
-            return; // a corner beside or behind the camera: no rectangle
-        const double cx = (double)r.x * x.x + (double)r.y * x.y + (double)r.z * x.z, cy = (double)r.x * y.x + (double)r.y * y.y + (double)r.z * y.z;
-        const double u = (-cx * f / cz + w / 2) / w, v = (cy * f / cz + h / 2) / h;
-        if (!(u == u) || !(v == v) || !(std::fabs(u) < 1e6) || !(std::fabs(v) < 1e6))
+// Which 8x8 tiles of a W x H frame a box can be seen in, jitter included.
+// In camera space a ray's direction is v + j: v the unit view direction of its pixel -- slopes (v.x / v.z, v.y / v.z), which
+// are linear in the pixel's (u, v) = (x / W, y / H) (Camera::getRayDirction, Include/Camera.hpp:33-47) --, j the jitter
+// turned into camera space, |j| <= js sqrt(3) =: e.  The ray can meet the box only if its slopes lie in the projection of
+// the box, which -- all eight corners in front of the camera, or there is no answer -- lies in the bounding rectangle of
+// the corners' slopes.  The jitter moves a slope by |j.x v.z - v.x j.z| / (v.z (v.z + j.z)) <= 2 e / (z0 (z0 - e)), z0 =
+// focal / |(w/2, h/2, focal)| the smallest v.z of the frame: 7.7 pixels at 1920 x 1080 with the reference's camera and its
+// 0.001.  The rectangle is widened by that (plus 5 % and half a pixel; the slab test's own rounding is eight orders of
+// magnitude below a pixel) and rounded outwards to whole tiles: no camera ray of a tile outside it meets the box.
+struct TileProjection {
+    double pos[3], x[3], y[3], z[3], f = 0, w = 0, h = 0, mx = 0, my = 0;
+    int W = 0, H = 0, tiles_x = 0, tiles_y = 0;
+    bool ok = false;
+    TileProjection(const rt_camera &c, int W_, int H_, float jitter) : W(W_), H(H_), tiles_x((W_ + 7) / 8), tiles_y((H_ + 7) / 8) {
+        const f3 p = mk3(c.position[0], c.position[1], c.position[2]);
+        const f3 zz = normalize3(mk3(c.look_at[0], c.look_at[1], c.look_at[2]) - p);
+        const f3 xx = normalize3(cross3(mk3(0.f, 1.f, 0.f), zz));
+        const f3 yy = cross3(zz, xx);
+        const float *src[4] = {&p.x, &xx.x, &yy.x, &zz.x};
+        double *dst[4] = {pos, x, y, z};
+        for (int a = 0; a < 4; a++)
+            for (int k = 0; k < 3; k++)
+                dst[a][k] = src[a][k];
+        f = c.focal_length;
+        w = c.width;
+        h = c.height;
+        if (!(f > 0.0) || !(w > 0.0) || !(h > 0.0) || !(jitter >= 0.0f))
             return;
-        u0 = u < u0 ? u : u0;
-        u1 = u > u1 ? u : u1;
-        v0 = v < v0 ? v : v0;
-        v1 = v > v1 ? v : v1;
+        for (int k = 0; k < 3; k++)
+            if (!(x[k] == x[k]) || !(y[k] == y[k]) || !(z[k] == z[k]))
+                return;
+        const double z0 = f / std::sqrt(w * w / 4 + h * h / 4 + f * f), e = (double)jitter * 1.7320508075688772 * 1.0001;
+        if (!(e < z0 / 2))
+            return;
+        const double slope = 2.0 * e / (z0 * (z0 - e));
+        mx = 1.05 * W * f * slope / w + 0.5;
+        my = 1.05 * H * f * slope / h + 0.5;
+        ok = true;
     }
-    // pixel x has u = x / W (CPUImageData::uvAt, Renderer/TraceMethods.hpp:30)
-    const double x0 = std::floor(u0 * W - mx), x1 = std::ceil(u1 * W + mx), y0 = std::floor(v0 * H - my), y1 = std::ceil(v1 * H + my);
-    auto tile_of = [](double p, int n_tiles, int extra) {
-        const double t = std::floor(p / 8.0) + extra;
-        return (int)(t < -1.0 ? -1.0 : t > (double)n_tiles ? (double)n_tiles : t);
-    };
-    out[0] = tile_of(x0, tiles_x, -1);
-    out[1] = tile_of(y0, tiles_y, -1);
-    out[2] = tile_of(x1, tiles_x, 1);
-    out[3] = tile_of(y1, tiles_y, 1);
+    // tiles [out[0], out[2]] x [out[1], out[3]] (possibly outside the frame, possibly empty); false: no answer for this box
+    bool tiles_of(const float box[6], int out[4]) const {
+        if (!ok)
+            return false;
+        double u0 = 1e30, u1 = -1e30, v0 = 1e30, v1 = -1e30;
+        for (int k = 0; k < 8; k++) {
+            const double r[3] = {(double)box[(k & 1) ? 3 : 0] - pos[0], (double)box[(k & 2) ? 4 : 1] - pos[1], (double)box[(k & 4) ? 5 : 2] - pos[2]};
+            const double cz = r[0] * z[0] + r[1] * z[1] + r[2] * z[2];
+            if (!(cz > 1e-4 * (std::fabs(r[0]) + std::fabs(r[1]) + std::fabs(r[2])) + 1e-30))
+                return false; // a corner beside or behind the camera (or not a number)
+            const double cx = r[0] * x[0] + r[1] * x[1] + r[2] * x[2], cy = r[0] * y[0] + r[1] * y[1] + r[2] * y[2];
+            const double u = (-cx * f / cz + w / 2) / w, v = (cy * f / cz + h / 2) / h;
+            if (!(std::fabs(u) < 1e6) || !(std::fabs(v) < 1e6))
+                return false;
+            u0 = u < u0 ? u : u0;
+            u1 = u > u1 ? u : u1;
+            v0 = v < v0 ? v : v0;
+            v1 = v > v1 ? v : v1;
+        }
+        // pixel x has u = x / W (CPUImageData::uvAt, Renderer/TraceMethods.hpp:30)
+        auto tile_of = [](double p, int n_tiles, int extra) {
+            const double t = std::floor(p / 8.0) + extra;
+            return (int)(t < -1.0 ? -1.0 : t > (double)n_tiles ? (double)n_tiles : t);
+        };
+        out[0] = tile_of(std::floor(u0 * W - mx), tiles_x, 0);
+        out[1] = tile_of(std::floor(v0 * H - my), tiles_y, 0);
+        out[2] = tile_of(std::ceil(u1 * W + mx), tiles_x, 0);
+        out[3] = tile_of(std::ceil(v1 * H + my), tiles_y, 0);
+        return true;
+    }
+};
+
+// The tiles outside which no camera ray can meet the scene's root box (the whole frame when there is no answer).
+void root_box_tiles(const rt_ctx *ctx, int W, int H, float jitter, int out[4]) {
+    const TileProjection tp(ctx->cam, W, H, jitter);
+    if (!tp.tiles_of(ctx->root_box, out)) {
+        out[0] = out[1] = 0;
+        out[2] = tp.tiles_x - 1;
+        out[3] = tp.tiles_y - 1;
+    }
+}
+
+// One byte per tile of the frame: 1 where some box of the scene's cut (SceneLayout::cut_boxes) can be seen, 0 where no
+// camera ray can meet any of them -- hence no leaf box: such a tile's samples are sky whatever the walk would do.  False
+// when there is no answer (a box beside or behind the camera, a box that is not finite, no cut): every tile is tested.
+bool camera_tile_mask(const rt_ctx *ctx, int W, int H, float jitter, std::vector<uint8_t> &mask) {
+    const TileProjection tp(ctx->cam, W, H, jitter);
+    if (!tp.ok || ctx->cut_boxes.empty())
+        return false;
+    mask.assign((size_t)tp.tiles_x * tp.tiles_y, 0);
+    for (size_t b = 0; b + 6 <= ctx->cut_boxes.size(); b += 6) {
+        int t[4];
+        if (!tp.tiles_of(&ctx->cut_boxes[b], t))
+            return false;
+        const int x0 = t[0] < 0 ? 0 : t[0], y0 = t[1] < 0 ? 0 : t[1], x1 = t[2] >= tp.tiles_x ? tp.tiles_x - 1 : t[2],
+                  y1 = t[3] >= tp.tiles_y ? tp.tiles_y - 1 : t[3];
+        for (int y = y0; y <= y1; y++)
+            if (x1 >= x0)
+                std::memset(&mask[(size_t)y * tp.tiles_x + x0], 1, (size_t)(x1 - x0 + 1));
+    }
+    return true;
 }
 
 double root_box_coverage(const rt_ctx *ctx) {
@@ -459,7 +525,8 @@ double root_box_coverage(const rt_ctx *ctx) {
 // most one unit of each kind beyond its share, 2 * 64 batches, hence kSlackBatches = 130.
 size_t queue_records(size_t items) { return items + kQueueSlack; }
 
-int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim, Plan &pl, const float4 *d_img_in = nullptr) {
+int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim, Plan &pl, const float4 *d_img_in = nullptr,
+              bool may_allocate = true) {
     if (!ctx->has_scene)
         return fail(ctx, RT_ERR_NO_SCENE, "Scene is not loaded.");
     if (!ctx->has_camera)
@@ -567,6 +634,43 @@ int make_plan(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, ui
         P.cam_ty0 = tiles[1];
         P.cam_tx1 = tiles[2];
         P.cam_ty1 = tiles[3];
+    }
+    // ... and, inside that rectangle, the tiles that can see a box of the scene's cut.  The mask is made again only when the
+    // camera, the frame size, the jitter or the scene has changed; launches still in flight read the old one, so the
+    // context's stream first waits for them (a stream-level wait) and then takes the copy.
+    P.cam_mask = nullptr;
+    // (a trace that counts the exact walk's tests leaves the mask out: the tiles it spares are tiles whose rays that walk looks at)
+    if (pl.camera && may_allocate && tuning().tile_mask != 0 && (!st || o.collect_stats == 2)) {
+        rt_ctx::MaskKey key{};
+        key.cam = ctx->cam;
+        key.W = W;
+        key.H = H;
+        key.jitter = o.jitter;
+        key.scene = ctx->scene_version;
+        if (!ctx->mask_valid || std::memcmp(&key, &ctx->mask_key, sizeof(key)) != 0) {
+            std::vector<uint8_t> mask;
+            ctx->mask_usable = camera_tile_mask(ctx, W, H, o.jitter, mask);
+            if (ctx->mask_usable) {
+                const int jrc = join_pipes(ctx);
+                if (jrc != RT_OK)
+                    return jrc;
+                if (mask.size() > ctx->cam_mask_cap) {
+                    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                    if (ctx->d_cam_mask) (void)hipFree(ctx->d_cam_mask);
+                    ctx->d_cam_mask = nullptr;
+                    ctx->cam_mask_cap = 0;
+                    RT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_cam_mask, mask.size()));
+                    ctx->cam_mask_cap = mask.size();
+                }
+                RT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_cam_mask, mask.data(), mask.size(), hipMemcpyHostToDevice, ctx->stream));
+                RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // (the copy reads a buffer that is about to go away)
+            }
+            std::memset(&ctx->mask_key, 0, sizeof(ctx->mask_key));
+            ctx->mask_key = key;
+            ctx->mask_valid = true;
+        }
+        if (ctx->mask_usable)
+            P.cam_mask = ctx->d_cam_mask;
     }
     P.deferred = nullptr;
     // Slice length: 32 ... 192 records swept on bare meshes, fields and meshes on a ground quad (128 is best or level with
@@ -988,7 +1092,7 @@ int launch_trace(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img,
 int launch_trace_noalloc(rt_ctx *ctx, int W, int H, int first, int count, float4 *d_img, uint32_t *d_prim) {
     Plan pl;
     {
-        const int prc = make_plan(ctx, W, H, first, count, d_img, d_prim, pl);
+        const int prc = make_plan(ctx, W, H, first, count, d_img, d_prim, pl, nullptr, false);
         if (prc != RT_OK)
             return prc;
     }
@@ -1182,11 +1286,14 @@ int upload_layout(rt_ctx *ctx, const SceneLayout &L) {
         const float4 a = L.fn[0], b = L.fn[1];
         const float rb[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
         std::memcpy(ctx->root_box, rb, sizeof(rb));
+        ctx->cut_boxes = L.cut_boxes;
     }
     ctx->fast_exact = L.nested;
     ctx->scene_bytes = (L.fn.size() + L.tp.size()) * sizeof(float4);
     ctx->n_nodes = L.n_ref;
     ctx->n_fnodes = L.n_fast;
+    ctx->scene_version++;
+    ctx->mask_valid = false;
     ctx->has_scene = true;
     return RT_OK;
 }
@@ -1219,6 +1326,7 @@ void destroy_single(rt_ctx *ctx) {
     if (ctx->ev_call) (void)hipEventDestroy(ctx->ev_call);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_cam_mask) (void)hipFree(ctx->d_cam_mask);
     for (auto &pp : ctx->pipes) {
         if (pp.ws.levels) (void)hipFree(pp.ws.levels);
         pp.ws.levels = nullptr;

@@ -1070,9 +1070,11 @@ __global__ void __launch_bounds__(256) k_camera(const KParams P) {
         {
             const int sb = P.S - s0 < 64 ? P.S - s0 : 64;
             unsigned long long mask = 0ull;
-            // a tile outside the widened projection of the scene's box (root_box_tiles): every sample is sky, nothing to test
+            // a tile outside the widened projection of the scene's box, or of every box of the scene's cut (root_box_tiles,
+            // camera_tile_mask): every sample is sky, nothing to test
             const int tile_x = (int)(tile - tile_y * (uint32_t)P.tiles_x);
-            const bool may_meet = tile_x >= P.cam_tx0 && tile_x <= P.cam_tx1 && (int)tile_y >= P.cam_ty0 && (int)tile_y <= P.cam_ty1;
+            const bool may_meet = tile_x >= P.cam_tx0 && tile_x <= P.cam_tx1 && (int)tile_y >= P.cam_ty0 && (int)tile_y <= P.cam_ty1 &&
+                                  (P.cam_mask == nullptr || P.cam_mask[tile] != 0);
             if (live) {
                 for (int s = 0; may_meet && s < sb; s++) {
                     uint32_t key;

@@ -29,7 +29,11 @@ struct SceneLayout {
     std::vector<uint8_t> leaf_class;
     bool prune = false;
     uint32_t n_irregular = 0;
+    // A cut through the fast tree: the boxes (pMin.xyz, pMax.xyz) of at most kCutBoxes subtrees that together hold every leaf.
+    // A ray that misses all of them meets no leaf box; the camera stage projects them to find the tiles worth testing.
+    std::vector<float> cut_boxes;
 };
+constexpr size_t kCutBoxes = 2048;
 
 // ------------------------------------------------------------------------------------------------
 // How far in front of its own leaf box can a triangle test report a hit?
@@ -447,6 +451,43 @@ int build_layout(const rt_node *nodes, uint32_t n_nodes, uint32_t root, const rt
     fastbvh::build(top_items, top_nodes);
     for (auto &tree : mesh_trees)
         fastbvh::build(tree.items, tree.nodes);
+
+    // The cut for the camera stage: the root's subtree is replaced by its two children, largest box first, until kCutBoxes
+    // boxes (or only leaves) are left.
+    if (!top_nodes.empty()) {
+        auto area = [&](uint32_t q) {
+            const double x = (double)top_nodes[q].bmax[0] - top_nodes[q].bmin[0], y = (double)top_nodes[q].bmax[1] - top_nodes[q].bmin[1],
+                         z = (double)top_nodes[q].bmax[2] - top_nodes[q].bmin[2];
+            return x * y + y * z + z * x;
+        };
+        std::vector<std::pair<double, uint32_t>> heap; // (area, node): interior nodes still to split
+        std::vector<uint32_t> cut;
+        auto put = [&](uint32_t q) {
+            if (top_nodes[q].item != 0xFFFFFFFFu) {
+                cut.push_back(q);
+            } else {
+                heap.emplace_back(area(q), q);
+                std::push_heap(heap.begin(), heap.end());
+            }
+        };
+        put(0u);
+        while (!heap.empty() && cut.size() + heap.size() < kCutBoxes) {
+            std::pop_heap(heap.begin(), heap.end());
+            const uint32_t q = heap.back().second;
+            heap.pop_back();
+            put(q + 1u);
+            put(q + 1u + top_nodes[q + 1u].size);
+        }
+        for (const auto &h : heap)
+            cut.push_back(h.second);
+        L.cut_boxes.reserve(6 * cut.size());
+        for (uint32_t q : cut) {
+            for (int k = 0; k < 3; k++)
+                L.cut_boxes.push_back(top_nodes[q].bmin[k]);
+            for (int k = 0; k < 3; k++)
+                L.cut_boxes.push_back(top_nodes[q].bmax[k]);
+        }
+    }
 
     // 3b. Flat scenes: the 16-bit grid over the root box that the compact and the wide form of the fast tree place their
     //     planes on, and the wide form's topology -- it decides the numbering of the triangle slots (see build_wide).

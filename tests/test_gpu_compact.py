@@ -182,7 +182,9 @@ def test_results_do_not_depend_on_the_tuning():
                 # no wide tree (the grid records' sliced walk with its re-fill hand-over), the wide tree without its distance
                 # limit, and with the camera rays of every scene through it
                 {"RT_WIDE": "0"}, {"RT_WIDE": "0", "RT_TAIL_RAYS": "3000"}, {"RT_PRUNE": "0"}, {"RT_PRUNE": "0", "RT_WAVE_CAMERA": "0"},
-                {"RT_WAVE_CAMERA": "0", "RT_CHUNK_SAMPLES": "7"}, {"RT_WIDE_BURST": "1"}, {"RT_WIDE_BURST": "9", "RT_WAVE_CAMERA": "0"}]
+                {"RT_WAVE_CAMERA": "0", "RT_CHUNK_SAMPLES": "7"}, {"RT_WIDE_BURST": "1"}, {"RT_WIDE_BURST": "9", "RT_WAVE_CAMERA": "0"},
+                # the camera stage without its tile mask
+                {"RT_TILE_MASK": "0"}]
     outs = []
     for env in settings:
         r = subprocess.run([sys.executable, "-c", TUNED, ROOT], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)

@@ -271,16 +271,17 @@ for name, spp in (("dragon18520_1080p", 16), ("dragon18520_full_ground_1080p", 4
 
 def test_wide_walk_and_its_distance_limit_at_full_size():
     """The bench workloads at 1920x1080 -- 33 M to 133 M camera rays and their bounces each -- under the default walk (wide
-    records, distance limit), without the limit and without the wide records (the grid records' walk): the same image and
+    records, distance limit, camera stage with its tile mask), without the limit, without the wide records (the grid records'
+    walk) and without the tile mask: the same image and
     the same primary ids, byte for byte.  Each setting in a process of its own (the switches are read once per process)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env in ({}, {"RT_PRUNE": "0"}, {"RT_WIDE": "0"}):
+    for env in ({}, {"RT_PRUNE": "0"}, {"RT_WIDE": "0"}, {"RT_TILE_MASK": "0"}):
         r = subprocess.run([sys.executable, "-c", FULL_SIZE, root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (env, r.stderr[-2000:])
         outs.append(r.stdout.strip().splitlines())
     assert len(outs[0]) == 3
-    assert outs[1] == outs[0] and outs[2] == outs[0]
+    assert outs[1] == outs[0] and outs[2] == outs[0] and outs[3] == outs[0]
