@@ -188,3 +188,13 @@ def test_tiles_that_cannot_see_the_scene_are_skipped_safely(tracer, dragon, jitt
         assert np.array_equal(pa, pb) and np.array_equal(bits(ia), bits(ib))
         assert sa.rays == sb.rays
         assert (pa != R.MISS).sum() > 50          # the scene is in the frame
+    # ... and against the oracle itself, the mask at work (no statistics asked for), the reference's and a larger jitter
+    if jitter <= 0.02:
+        _, os_ = dragon
+        cam = cams[2]
+        tracer.set_camera(cam)
+        tracer.set_options(bounce_limit=3, seed=11, jitter=jitter, camera_stage=R.CAMERA_SEPARATE)
+        img, prim, st = tracer.trace(320, 180, 1, 2, want_primary=True)
+        opt = O.make_options(bounce_limit=3, seed=11, jitter=jitter, trig=O.TRIG_POLY)
+        oimg, oprim, ost = os_.render(oracle_camera(cam), opt, 320, 180, 1, 2, want_primary=True)
+        assert np.array_equal(prim, oprim) and np.array_equal(bits(img), bits(oimg)) and st.rays == ost.rays
